@@ -1,0 +1,156 @@
+"""ctypes binding of ``libifcbk.so`` (the C-ABI declared in ``include/ifcbk.h``).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, a ``RuntimeError``
+is raised.  Nothing here imports the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libifcbk.so')
+
+BF16, F32 = 0, 1
+
+(OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
+ OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
+ OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK) = range(1, 20)
+
+OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
+            7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
+            13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
+            19: 'dropout_mask'}
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('N', 'H', 'W', 'C', 'ldx', 'K', 'R', 'S', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'P', 'Q',
+                 'ldy', 'Cw', 'dtype')]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('M', 'C', 'ldx', 'ldy', 'relu', 'dtype')] + \
+               [('eps', C.c_float), ('momentum', C.c_float)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('N', 'H', 'W', 'C', 'ldx', 'R', 'S', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'P', 'Q', 'ldy',
+                 'dtype')]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('N', 'HW', 'C', 'ldx', 'NC', 'dtype')] + [('keep_scale', C.c_float)]
+
+
+class RoiDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('n_img', 'S', 'in_channels', 'out_channels', 'flip_bits_valid', 'dtype')] + \
+               [('mean', C.c_float * 3), ('std', C.c_float * 3), ('tin_scale', C.c_float * 3),
+                ('tin_shift', C.c_float * 3)]
+
+
+class _OpU(C.Union):
+    _fields_ = [('conv', ConvDesc), ('bn', BnDesc), ('pool', PoolDesc), ('head', HeadDesc)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('p', C.c_void_p * 12), ('i', C.c_int64 * 4),
+                ('f', C.c_float * 8), ('u', _OpU)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_PROTOS = {
+    'ifcbk_version': (C.c_char_p, []),
+    'ifcbk_ctx_create': (_i, [_i, C.POINTER(_vp)]),
+    'ifcbk_ctx_destroy': (_i, [_vp]),
+    'ifcbk_ctx_reserve': (_i, [_vp, _sz]),
+    'ifcbk_ctx_workspace_bytes': (_sz, [_vp]),
+    'ifcbk_last_error': (C.c_char_p, [_vp]),
+    'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    'ifcbk_conv2d_dgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    'ifcbk_conv2d_wgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    'ifcbk_conv2d_wgrad_workspace': (_sz, [C.POINTER(ConvDesc)]),
+    'ifcbk_conv2d_fwd_mblocks': (_i, [C.POINTER(ConvDesc)]),
+    'ifcbk_weight_pack': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    'ifcbk_bn_finalize': (_i, [_vp, C.POINTER(BnDesc), _vp, _i] + [_vp] * 9),
+    'ifcbk_bn_apply': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'ifcbk_bn_bwd': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp,
+                          _i, _vp]),
+    'ifcbk_maxpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _vp]),
+    'ifcbk_maxpool_bwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp]),
+    'ifcbk_avgpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp]),
+    'ifcbk_avgpool_bwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _i, _vp]),
+    'ifcbk_head_fwd': (_i, [_vp, C.POINTER(HeadDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifcbk_head_bwd': (_i, [_vp, C.POINTER(HeadDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'ifcbk_dropout_mask': (_i, [_vp, _vp, C.c_int64, _f, C.c_uint64, C.c_uint64, _vp]),
+    'ifcbk_softmax_xent': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
+    'ifcbk_softmax': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'ifcbk_adam_flat': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _f, _vp]),
+    'ifcbk_sgd_flat': (_i, [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp]),
+    'ifcbk_roi_preprocess': (_i, [_vp, C.POINTER(RoiDesc), _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'ifcbk_roi_preprocess_workspace': (_sz, [C.POINTER(RoiDesc), _i, _i]),
+    'ifcbk_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp]),
+    'ifcbk_nhwc_to_nchw_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ifcbk_run_program': (_i, [_vp, C.POINTER(Op), _i, _vp, C.POINTER(_f)]),
+    'ifcbk_op_cost': (_i, [C.POINTER(Op), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib = None
+
+
+def load():
+    """Load libifcbk.so (built by ``__graft_entry__.build()`` / ``make -C ifcb_classifier_amd/csrc``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libifcbk.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
+                               'g.build()"` (hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class Context:
+    """One ifcbk_ctx per (process, GPU).  ``call`` turns non-zero returns into RuntimeError."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.ifcbk_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError('ifcbk_ctx_create(device=%d) failed with %d (no usable HIP device?)' % (device, rc))
+        self.h = h
+        self.device = device
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (name, rc, self.lib.ifcbk_last_error(self.h).decode()))
+
+    def reserve(self, nbytes):
+        self.call('ifcbk_ctx_reserve', int(nbytes))
+
+    def run_program(self, ops, n, stream, op_ms=None):
+        self.call('ifcbk_run_program', ops, int(n), stream, op_ms)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.ifcbk_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def ptr(t):
+    """raw device pointer of a torch tensor (or None)."""
+    return None if t is None else _vp(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return _vp(torch.cuda.current_stream().cuda_stream)

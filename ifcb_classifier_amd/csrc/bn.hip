@@ -1,0 +1,280 @@
+// BatchNorm (train/eval) fused with ReLU and the resnet residual add; HBM-bound elementwise/reduction
+// kernels: every access is a 16-byte chunk of 8 bf16 channels, consecutive lanes on consecutive chunks.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- finalize
+// one block per 16 channels; 64 row groups stride over the per-M-block partials written by the conv epilogue
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, int mblocks, int C, double invM,
+                                                            double unbias, const float* gamma, const float* beta,
+                                                            float* rmean, float* rvar, float* mean_o, float* invstd_o,
+                                                            float* scale, float* shift, float eps, float momentum) {
+    __shared__ double s1[64][16], s2[64][16];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + c;
+    double a = 0.0, b = 0.0;
+    if (ch < C) {
+        for (int mb = rg; mb < mblocks; mb += 64) {
+            a += (double)part[((size_t)mb * 2 + 0) * C + ch];
+            b += (double)part[((size_t)mb * 2 + 1) * C + ch];
+        }
+    }
+    s1[rg][c] = a;
+    s2[rg][c] = b;
+    __syncthreads();
+    if (threadIdx.x < 16 && ch < C) {
+        double sa = 0.0, sb = 0.0;
+        for (int i = 0; i < 64; ++i) {
+            sa += s1[i][c];
+            sb += s2[i][c];
+        }
+        double mean = sa * invM;
+        double var = sb * invM - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma[ch], sc = g * invstd;
+        mean_o[ch] = (float)mean;
+        invstd_o[ch] = invstd;
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - (float)mean * sc;
+        if (rmean) {
+            rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+            rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)(var * unbias);
+        }
+    }
+}
+
+__global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* beta, const float* rmean,
+                                     const float* rvar, float* scale, float* shift, float eps) {
+    int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= C) return;
+    float sc = gamma[ch] / sqrtf(rvar[ch] + eps);
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - rmean[ch] * sc;
+}
+
+// ---------------------------------------------------------------- apply
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* x, int ldx, const float* scale, const float* shift,
+                                                        const bf16_t* res, int ldr, bf16_t* y, int ldy, int64_t M,
+                                                        int cpr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cpr) return;
+    int64_t m = i / cpr;
+    int c = (int)(i - m * cpr) * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(x + m * ldx + c);
+    float f[8], sc[8], sh[8];
+    unpack8(v, f);
+    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + c);
+    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
+    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + c);
+    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + c + 4);
+    float r[8];
+    if (RES) {
+        uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
+        unpack8(rv, r);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float o = f[j] * sc[j] + sh[j];
+        if (RES) o += r[j];
+        if (RELU) o = fmaxf(o, 0.f);
+        f[j] = o;
+    }
+    *reinterpret_cast<uint4*>(y + m * ldy + c) = pack8(f);
+}
+
+// ---------------------------------------------------------------- backward
+// pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks (64 channels) x 32 rows in flight
+constexpr int BWD_ROWS = 1024;
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
+                                                             const bf16_t* dy, int lddy, const float* mean,
+                                                             const float* invstd, float* part, int64_t M, int C) {
+    __shared__ float red[4][2][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cc = t & 7, r0 = t >> 3;
+    const int c = blockIdx.y * 64 + cc * 8;
+    const int64_t mbeg = (int64_t)blockIdx.x * BWD_ROWS;
+    const int64_t mend = mbeg + BWD_ROWS < M ? mbeg + BWD_ROWS : M;
+    float sb[8], sg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sb[j] = sg[j] = 0.f;
+    if (c < C) {
+        float mu[8], is[8];
+        *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(mean + c);
+        *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(mean + c + 4);
+        *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(invstd + c);
+        *reinterpret_cast<float4*>(is + 4) = *reinterpret_cast<const float4*>(invstd + c + 4);
+        for (int64_t m = mbeg + r0; m < mend; m += 32) {
+            float fx[8], fy[8], fd[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
+            unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
+            if (RELU) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float dz = fd[j];
+                if (RELU) dz = fy[j] > 0.f ? dz : 0.f;
+                sb[j] += dz;
+                sg[j] += dz * ((fx[j] - mu[j]) * is[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sb[j] += __shfl_xor(sb[j], off);
+            sg[j] += __shfl_xor(sg[j], off);
+        }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[wave][0][cc * 8 + j] = sb[j];
+            red[wave][1][cc * 8 + j] = sg[j];
+        }
+    }
+    __syncthreads();
+    if (t < 128) {
+        int which = t >> 6, n = t & 63;
+        int ch = blockIdx.y * 64 + n;
+        if (ch < C) {
+            float s = red[0][which][n] + red[1][which][n] + red[2][which][n] + red[3][which][n];
+            part[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
+        }
+    }
+}
+
+// pass 2: sum the row-tile partials (fixed order) -> dbeta, dgamma (+ temp copy used by pass 3)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int ntiles, int C, float* dgamma,
+                                                               float* dbeta, float* tmp, int accumulate) {
+    __shared__ double s[2][16][16];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + c;
+    double a = 0.0, b = 0.0;
+    if (ch < C)
+        for (int i = rg; i < ntiles; i += 16) {
+            a += (double)part[((size_t)i * 2 + 0) * C + ch];
+            b += (double)part[((size_t)i * 2 + 1) * C + ch];
+        }
+    s[0][rg][c] = a;
+    s[1][rg][c] = b;
+    __syncthreads();
+    if (threadIdx.x < 16 && ch < C) {
+        double sa = 0.0, sg = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            sa += s[0][i][c];
+            sg += s[1][i][c];
+        }
+        tmp[ch] = (float)sa;        // dbeta
+        tmp[C + ch] = (float)sg;    // dgamma
+        dbeta[ch] = accumulate ? dbeta[ch] + (float)sa : (float)sa;
+        dgamma[ch] = accumulate ? dgamma[ch] + (float)sg : (float)sg;
+    }
+}
+
+// pass 3: dx (and the residual branch gradient)
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
+                                                         const bf16_t* dy, int lddy, const float* gamma,
+                                                         const float* mean, const float* invstd, const float* tmp,
+                                                         bf16_t* dx, int lddx, bf16_t* dres, int lddres, int dres_acc,
+                                                         int64_t M, int C, float invM) {
+    const int cpr = C / 8;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cpr) return;
+    int64_t m = i / cpr;
+    int c = (int)(i - m * cpr) * 8;
+    float fx[8], fy[8], fd[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
+    unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
+    if (RELU) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float dz = fd[j];
+        if (RELU) dz = fy[j] > 0.f ? dz : 0.f;
+        fd[j] = dz;
+        float is = invstd[c + j];
+        float xhat = (fx[j] - mean[c + j]) * is;
+        o[j] = gamma[c + j] * is * (dz - tmp[c + j] * invM - xhat * tmp[C + c + j] * invM);
+    }
+    if (dres) {
+        bf16_t* rp = dres + m * lddres + c;
+        if (dres_acc) {
+            float fr[8];
+            unpack8(*reinterpret_cast<const uint4*>(rp), fr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fd[j] += fr[j];
+        }
+        *reinterpret_cast<uint4*>(rp) = pack8(fd);
+    }
+    *reinterpret_cast<uint4*>(dx + m * lddx + c) = pack8(o);
+}
+
+}  // namespace
+
+extern "C" int ifcbk_bn_finalize(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const float* part, int mblocks,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    if (!d || d->C <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_finalize: bad desc");
+    hipStream_t st = (hipStream_t)stream;
+    if (part) {
+        double M = (double)d->M;
+        double unbias = d->M > 1 ? M / (M - 1.0) : 1.0;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d->C, 16)), dim3(1024), 0, st, part, mblocks, d->C, 1.0 / M,
+                           unbias, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, d->eps,
+                           d->momentum);
+    } else {
+        hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(d->C, 256)), dim3(256), 0, st, d->C, gamma, beta,
+                           (const float*)running_mean, (const float*)running_var, scale, shift, d->eps);
+    }
+    IFCBK_LAUNCH_CHECK(ctx, "bn_finalize");
+    return 0;
+}
+
+extern "C" int ifcbk_bn_apply(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const float* scale,
+                              const float* shift, const void* residual, int ldr, void* y, void* stream) {
+    if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: bad desc");
+    int cpr = d->C / 8;
+    int64_t total = (int64_t)d->M * cpr;
+    dim3 grid(cdiv(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* xx = (const bf16_t*)x;
+    const bf16_t* rr = (const bf16_t*)residual;
+    bf16_t* yy = (bf16_t*)y;
+    if (d->relu && rr) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
+    else if (d->relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
+    else if (rr) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_apply");
+    return 0;
+}
+
+extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy,
+                            int lddy, const float* gamma, const float* mean, const float* invstd, void* dx, int lddx,
+                            void* dres, int lddres, int dres_accumulate, float* dgamma, float* dbeta,
+                            int param_accumulate, void* stream) {
+    if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: bad desc");
+    const int C = d->C;
+    const int64_t M = d->M;
+    int ntiles = cdiv(M, BWD_ROWS);
+    size_t need = ((size_t)ntiles * 2 * C + 2 * C) * sizeof(float);
+    if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd: workspace %zu > reserved %zu", need, ctx->ws_bytes);
+    float* part = (float*)ctx->ws;
+    float* tmp = part + (size_t)ntiles * 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* xx = (const bf16_t*)x; const bf16_t* yy = (const bf16_t*)y; const bf16_t* dd = (const bf16_t*)dy;
+    dim3 g1(ntiles, cdiv(C, 64));
+    if (d->relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, part, M, C);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, part, M, C);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
+    int64_t total = M * (C / 8);
+    float invM = (float)(1.0 / (double)M);
+    if (d->relu) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
+    return 0;
+}

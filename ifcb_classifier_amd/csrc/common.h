@@ -1,0 +1,80 @@
+// Shared device/host helpers for libifcbk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/ifcbk.h"
+
+struct ifcbk_ctx {
+    int device;
+    void* ws;            // workspace arena (split-K slabs, resize tables)
+    size_t ws_bytes;
+    hipEvent_t* ev;      // profiling events for ifcbk_run_program
+    int n_ev;
+    char err[512];
+};
+
+#define IFCBK_FAIL(ctx, code, ...)                                   \
+    do {                                                             \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+        return (code);                                               \
+    } while (0)
+
+#define IFCBK_HIP(ctx, expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) IFCBK_FAIL(ctx, IFCBK_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define IFCBK_LAUNCH_CHECK(ctx, name)                                                     \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess) IFCBK_FAIL(ctx, IFCBK_EHIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even, NaN preserved (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// exact unsigned division by a runtime constant for n < 2^31 (host builds, device applies)
+struct fastdiv_t {
+    uint32_t mul, shift, d;
+};
+static inline fastdiv_t make_fastdiv(uint32_t d) {
+    fastdiv_t f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    f.shift = s;
+    f.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const fastdiv_t& f) {
+    return (__umulhi(n, f.mul) + n) >> f.shift;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

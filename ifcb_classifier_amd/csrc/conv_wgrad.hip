@@ -1,0 +1,289 @@
+// Convolution weight-gradient on MFMA (gfx950): dW[k][r,s,c] = sum_pix dy[pix][k] * x[gather(pix,r,s)][c].
+//
+// GEMM view: M' = output channels k, N' = (r,s,c) columns, reduction over pixels (up to 5.7 M).  Both
+// operands are stored pixel-major (NHWC), i.e. the reduction index is the SLOW axis of both, which a
+// k-contiguous MFMA fragment cannot read directly.  The tiles are staged untransposed (coalesced 16-byte
+// chunks) and the fragments are read with ds_read_b64_tr_b16 -- gfx950's transposing LDS read -- so no
+// transposed copy of any activation is ever written to HBM.
+//
+// Split-K over pixel ranges with fp32 partial slabs in the ctx workspace, summed in a fixed order by
+// wgrad_reduce (bitwise reproducible; no float atomics).
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* slab;      // [nsplit][K][RSC]
+    int H, W, C, ldx;
+    int K, R, S;
+    int P, Q, ldy;
+    int sh, sw, ph, pw;
+    int M;            // N*P*Q pixels
+    int RSC;
+    int split_len;    // pixels per split (multiple of 32)
+    int tilesN;       // column tiles
+    fastdiv_t fPQ, fQ;
+};
+
+constexpr int NTHREADS = 256;
+constexpr int BKP = 32;     // pixels per step
+constexpr int BNW = 128;    // columns per block
+constexpr int LDB = BNW + 16;
+
+__device__ __forceinline__ s16x4_t tr_read(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(p));
+}
+
+template <int MT>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
+    constexpr int BMW = 32 * MT;
+    constexpr int LDA = BMW + 16;
+    constexpr int CA = BMW / 8;                      // dy chunks per pixel
+    constexpr int NA = (BKP * CA + NTHREADS - 1) / NTHREADS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BKP * LDA + 2 * BKP * LDB];
+    bf16_t* sA = smem;
+    bf16_t* sB = smem + 2 * BKP * LDA;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
+    const int k0 = mtile * BMW, n0 = ntile * BNW;
+    const int split = blockIdx.y;
+    const int pix_begin = split * a.split_len;
+    const int pix_end = min(pix_begin + a.split_len, a.M);
+
+    // B (gathered x): thread -> column chunk cb, pixel rows pb and pb+16
+    const int cb = t & 15, pb = t >> 4;
+    int br, bs, bc;
+    bool colvalid;
+    {
+        int j = n0 + cb * 8;
+        colvalid = j < a.RSC;
+        int jj = colvalid ? j : 0;
+        int rs = jj / a.C;
+        bc = jj - rs * a.C;
+        br = rs / a.S;
+        bs = rs - br * a.S;
+    }
+    // A (dy): flat chunk ids
+    int arow[NA], acol[NA];
+    bool avalid[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int e = t + NTHREADS * i;
+        arow[i] = e / CA;
+        acol[i] = e - arow[i] * CA;
+        avalid[i] = (e < BKP * CA) && (k0 + acol[i] * 8 < a.K);
+    }
+
+    uint4 ra[NA], rb[2];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_tiles = [&](int pix0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int pix = pix0 + arow[i];
+            bool v = avalid[i] && pix < pix_end;
+            ra[i] = v ? *reinterpret_cast<const uint4*>(a.dy + (size_t)pix * a.ldy + k0 + acol[i] * 8) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int pix = pix0 + pb + 16 * i;
+            bool v = colvalid && pix < pix_end;
+            uint32_t pp = v ? (uint32_t)pix : 0u;
+            uint32_t n = fdiv(pp, a.fPQ);
+            uint32_t rem = pp - n * a.fPQ.d;
+            uint32_t p = fdiv(rem, a.fQ);
+            uint32_t q = rem - p * a.fQ.d;
+            int hi = (int)p * a.sh - a.ph + br, wi = (int)q * a.sw - a.pw + bs;
+            v = v && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+            rb[i] = v ? *reinterpret_cast<const uint4*>(a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.ldx + bc) : zero4;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (t + NTHREADS * i < BKP * CA)
+                *reinterpret_cast<uint4*>(sA + buf * BKP * LDA + arow[i] * LDA + acol[i] * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(sB + buf * BKP * LDB + (pb + 16 * i) * LDB + cb * 8) = rb[i];
+    };
+
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (pix_end - pix_begin + BKP - 1) / BKP;
+    if (nsteps > 0) {
+        load_tiles(pix_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    // transposing fragment reads: lane (g, q, p) addresses LDS row 4g+q (then +16), columns col0+4p..+3
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    const int trow = 4 * g + lq;
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tiles(pix_begin + (st + 1) * BKP);
+        bf16x8_t fa[MT], fb[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16_t* base = sA + buf * BKP * LDA + trow * LDA + wm * (MT * 16) + mt * 16 + 4 * lp;
+            s16x4_t lo = tr_read(base), hi = tr_read(base + 16 * LDA);
+            fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const bf16_t* base = sB + buf * BKP * LDB + trow * LDB + wn * 64 + nt * 16 + 4 * lp;
+            s16x4_t lo = tr_read(base), hi = tr_read(base + 16 * LDB);
+            fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        if (st + 1 < nsteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // slab store: lane holds rows k = 4g+j, column l&15
+    float* out = a.slab + (size_t)split * a.K * a.RSC;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int col = n0 + wn * 64 + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = k0 + wm * (MT * 16) + mt * 16 + 4 * g + j;
+                if (k < a.K && col < a.RSC) out[(size_t)k * a.RSC + col] = acc[mt][nt][j];
+            }
+        }
+}
+
+// dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]
+__global__ void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw, int accumulate) {
+    int64_t total = (int64_t)K * RS * Cw;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cw = (int)(i % Cw);
+    int64_t krs = i / Cw;
+    int64_t src = krs * C + cw;
+    int64_t stride = (int64_t)K * RS * C;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * stride + src];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+int pick_mt(int K) {
+    int best = 1;
+    long bestc = -1;
+    for (int mt = 1; mt <= 5; ++mt) {
+        int bm = 32 * mt;
+        long c = (long)cdiv(K, bm) * (bm + 48);
+        if (bestc < 0 || c < bestc || (c == bestc && mt > best)) { bestc = c; best = mt; }
+    }
+    return best;
+}
+
+struct Plan { int mt, tilesM, tilesN, nsplit, split_len; size_t ws; };
+
+Plan make_plan(const ifcbk_conv_desc* d) {
+    Plan p;
+    int64_t M = (int64_t)d->N * d->P * d->Q;
+    int RSC = d->R * d->S * d->C;
+    p.mt = pick_mt(d->K);
+    p.tilesM = cdiv(d->K, 32 * p.mt);
+    p.tilesN = cdiv(RSC, BNW);
+    int tiles = p.tilesM * p.tilesN;
+    int64_t steps = (M + BKP - 1) / BKP;
+    int64_t ns = cdiv(1024, tiles);
+    int64_t maxsplit = steps / 8 > 0 ? steps / 8 : 1;
+    if (ns > maxsplit) ns = maxsplit;
+    if (ns < 1) ns = 1;
+    int64_t len = ((steps + ns - 1) / ns) * BKP;
+    ns = (M + len - 1) / len;
+    p.nsplit = (int)ns;
+    p.split_len = (int)len;
+    p.ws = (size_t)ns * d->K * RSC * sizeof(float);
+    return p;
+}
+
+template <int MT>
+void launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
+    hipLaunchKernelGGL(conv_wgrad_bf16<MT>, dim3(p.tilesM * p.tilesN, p.nsplit), dim3(NTHREADS), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc* d) { return make_plan(d).ws; }
+
+extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* dw,
+                                  int accumulate, void* stream) {
+    if (!d || d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad: only bf16 storage is implemented");
+    if (d->C % 8 || d->K % 8 || d->ldx % 8 || d->ldy % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: channels must be multiples of 8");
+    if (d->Cw > d->C || d->Cw <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: bad Cw");
+    if ((int64_t)d->N * d->P * d->Q >= (1ll << 31) || (int64_t)d->N * d->H * d->W >= (1ll << 31))
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: pixel count exceeds 2^31");
+    Plan p = make_plan(d);
+    if (p.ws > ctx->ws_bytes)
+        IFCBK_FAIL(ctx, IFCBK_ENOMEM, "wgrad: workspace %zu > reserved %zu (call ifcbk_ctx_reserve)", p.ws, ctx->ws_bytes);
+    WgradArgs a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws;
+    a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+    a.K = d->K; a.R = d->R; a.S = d->S; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.M = d->N * d->P * d->Q; a.RSC = d->R * d->S * d->C;
+    a.split_len = p.split_len; a.tilesN = p.tilesN;
+    a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.mt) {
+        case 1: launch<1>(a, p, st); break;
+        case 2: launch<2>(a, p, st); break;
+        case 3: launch<3>(a, p, st); break;
+        case 4: launch<4>(a, p, st); break;
+        default: launch<5>(a, p, st); break;
+    }
+    IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
+    int64_t total = (int64_t)d->K * d->R * d->S * d->Cw;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ctx->ws, dw, p.nsplit,
+                       d->K, d->R * d->S, d->C, d->Cw, accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
+    return 0;
+}
+
+// ---------------------------------------------------------------- weight pack
+namespace {
+// w[k][rs][c] (bf16, c<C zero padded) and wT[c][RS-1-rs][k]
+__global__ void weight_pack_kernel(const float* wm, bf16_t* w, bf16_t* wT, int K, int RS, int C, int Cw) {
+    int64_t total = (int64_t)K * RS * C;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t krs = i / C;
+    int rs = (int)(krs % RS);
+    int k = (int)(krs / RS);
+    float v = c < Cw ? wm[krs * Cw + c] : 0.f;
+    bf16_t b = f2bf(v);
+    w[i] = b;
+    if (wT) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = b;
+}
+}  // namespace
+
+extern "C" int ifcbk_weight_pack(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const float* w_master, void* w, void* wT,
+                                 void* stream) {
+    if (!d || d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "weight_pack: only bf16");
+    int64_t total = (int64_t)d->K * d->R * d->S * d->C;
+    hipLaunchKernelGGL(weight_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_master,
+                       (bf16_t*)w, (bf16_t*)wT, d->K, d->R * d->S, d->C, d->Cw);
+    IFCBK_LAUNCH_CHECK(ctx, "weight_pack");
+    return 0;
+}

@@ -1,0 +1,154 @@
+// ctx lifetime, workspace, error text and the program runner of libifcbk.
+#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+
+extern "C" const char* ifcbk_version(void) { return "ifcbk 0.1 (gfx950, bf16 MFMA)"; }
+
+extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
+    if (!out) return IFCBK_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return IFCBK_EHIP;
+    ifcbk_ctx* c = (ifcbk_ctx*)calloc(1, sizeof(ifcbk_ctx));
+    if (!c) return IFCBK_ENOMEM;
+    c->device = device;
+    *out = c;
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
+    if (!c) return IFCBK_OK;
+    if (c->ws) (void)hipFree(c->ws);
+    for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
+    free(c->ev);
+    free(c);
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
+    if (!c) return IFCBK_EINVAL;
+    if (bytes <= c->ws_bytes) return IFCBK_OK;
+    IFCBK_HIP(c, hipSetDevice(c->device));
+    IFCBK_HIP(c, hipDeviceSynchronize());
+    if (c->ws) IFCBK_HIP(c, hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    bytes = (bytes + 255) & ~(size_t)255;
+    IFCBK_HIP(c, hipMalloc(&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return IFCBK_OK;
+}
+
+extern "C" size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* c) { return c ? c->ws_bytes : 0; }
+
+extern "C" const char* ifcbk_last_error(ifcbk_ctx* c) { return c ? c->err : "null ctx"; }
+
+static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
+    void* const* p = o->p;
+    const int acc = o->flags & 1, pacc = (o->flags >> 1) & 1;
+    switch (o->kind) {
+        case IFCBK_OP_CONV_FWD: return ifcbk_conv2d_fwd(c, &o->u.conv, p[0], p[1], p[2], (float*)p[3], st);
+        case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
+        case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
+        case IFCBK_OP_WEIGHT_PACK: return ifcbk_weight_pack(c, &o->u.conv, (const float*)p[0], p[1], p[2], st);
+        case IFCBK_OP_BN_FINALIZE:
+            return ifcbk_bn_finalize(c, &o->u.bn, (const float*)p[0], (int)o->i[0], (const float*)p[1], (const float*)p[2],
+                                     (float*)p[3], (float*)p[4], (float*)p[5], (float*)p[6], (float*)p[7], (float*)p[8], st);
+        case IFCBK_OP_BN_APPLY:
+            return ifcbk_bn_apply(c, &o->u.bn, p[0], (const float*)p[1], (const float*)p[2], p[3], (int)o->i[0], p[4], st);
+        case IFCBK_OP_BN_BWD:
+            return ifcbk_bn_bwd(c, &o->u.bn, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
+                                (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc, (float*)p[8], (float*)p[9],
+                                pacc, st);
+        case IFCBK_OP_MAXPOOL_FWD: return ifcbk_maxpool_fwd(c, &o->u.pool, p[0], p[1], (uint8_t*)p[2], st);
+        case IFCBK_OP_MAXPOOL_BWD: return ifcbk_maxpool_bwd(c, &o->u.pool, p[0], (const uint8_t*)p[1], p[2], acc, st);
+        case IFCBK_OP_AVGPOOL_FWD: return ifcbk_avgpool_fwd(c, &o->u.pool, p[0], p[1], st);
+        case IFCBK_OP_AVGPOOL_BWD: return ifcbk_avgpool_bwd(c, &o->u.pool, p[0], p[1], acc, st);
+        case IFCBK_OP_HEAD_FWD:
+            return ifcbk_head_fwd(c, &o->u.head, p[0], (const uint8_t*)p[1], (const float*)p[2], (const float*)p[3],
+                                  (float*)p[4], (float*)p[5], st);
+        case IFCBK_OP_HEAD_BWD:
+            return ifcbk_head_bwd(c, &o->u.head, (const float*)p[0], (const float*)p[1], (const uint8_t*)p[2],
+                                  (const float*)p[3], (float*)p[4], (float*)p[5], p[6], (int)o->i[0], pacc, st);
+        case IFCBK_OP_SOFTMAX_XENT:
+            return ifcbk_softmax_xent(c, (const float*)p[0], (const int64_t*)p[1], (int)o->i[0], (int)o->i[1], o->f[0],
+                                      (float*)p[2], acc, (float*)p[3], st);
+        case IFCBK_OP_SOFTMAX: return ifcbk_softmax(c, (const float*)p[0], (int)o->i[0], (int)o->i[1], (float*)p[1], st);
+        case IFCBK_OP_ADAM:
+            return ifcbk_adam_flat(c, (float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], o->i[0], o->f[0], o->f[1],
+                                   o->f[2], o->f[3], o->f[4], (int)o->i[1], o->f[5], st);
+        case IFCBK_OP_MEMSET:
+            IFCBK_HIP(c, hipMemsetAsync(p[0], (int)o->i[1], (size_t)o->i[0], (hipStream_t)st));
+            return 0;
+        case IFCBK_OP_COPY2D:
+            IFCBK_HIP(c, hipMemcpy2DAsync(p[0], (size_t)o->i[0], p[1], (size_t)o->i[1], (size_t)o->i[2], (size_t)o->i[3],
+                                          hipMemcpyDeviceToDevice, (hipStream_t)st));
+            return 0;
+        case IFCBK_OP_DROPOUT_MASK:
+            return ifcbk_dropout_mask(c, (uint8_t*)p[0], o->i[0], o->f[0], (uint64_t)o->i[1], (uint64_t)o->i[2], st);
+        default: IFCBK_FAIL(c, IFCBK_EINVAL, "run_program: unknown op kind %d", o->kind);
+    }
+}
+
+extern "C" int ifcbk_run_program(ifcbk_ctx* c, const ifcbk_op* ops, int n, void* stream, float* op_ms) {
+    if (!c || (!ops && n > 0)) return IFCBK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (op_ms) {
+        if (c->n_ev < n + 1) {
+            hipEvent_t* ev = (hipEvent_t*)realloc(c->ev, sizeof(hipEvent_t) * (n + 1));
+            if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "run_program: event pool");
+            c->ev = ev;
+            for (int i = c->n_ev; i < n + 1; ++i) IFCBK_HIP(c, hipEventCreate(&c->ev[i]));
+            c->n_ev = n + 1;
+        }
+        IFCBK_HIP(c, hipEventRecord(c->ev[0], st));
+    }
+    for (int i = 0; i < n; ++i) {
+        int e = run_one(c, &ops[i], stream);
+        if (e) {
+            size_t L = strlen(c->err);
+            snprintf(c->err + L, sizeof(c->err) - L, " [op %d kind %d]", i, ops[i].kind);
+            return e;
+        }
+        if (op_ms) IFCBK_HIP(c, hipEventRecord(c->ev[i + 1], st));
+    }
+    if (op_ms) {
+        IFCBK_HIP(c, hipStreamSynchronize(st));
+        for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->ev[i], c->ev[i + 1]));
+    }
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
+    double fl = 0, by = 0;
+    switch (o->kind) {
+        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD: {
+            const ifcbk_conv_desc& d = o->u.conv;
+            double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
+            fl = 2.0 * mac;
+            double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
+                   wb = (double)d.K * d.R * d.S * d.C * 2;
+            by = xin + yout + wb;
+            break;
+        }
+        case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;
+        case IFCBK_OP_BN_BWD: by = (double)o->u.bn.M * o->u.bn.C * (2.0 * (o->u.bn.relu ? 6 : 4) + 2 + (o->p[7] ? 2 : 0)); break;
+        case IFCBK_OP_MAXPOOL_FWD: case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_MAXPOOL_BWD: case IFCBK_OP_AVGPOOL_BWD: {
+            const ifcbk_pool_desc& d = o->u.pool;
+            by = ((double)d.N * d.H * d.W + (double)d.N * d.P * d.Q) * d.C * 2;
+            break;
+        }
+        case IFCBK_OP_HEAD_FWD: case IFCBK_OP_HEAD_BWD: {
+            const ifcbk_head_desc& d = o->u.head;
+            fl = 2.0 * d.N * d.C * d.NC * (o->kind == IFCBK_OP_HEAD_BWD ? 2 : 1);
+            by = (double)d.N * d.HW * d.C * 2;
+            break;
+        }
+        case IFCBK_OP_ADAM: by = (double)o->i[0] * 28; break;
+        default: break;
+    }
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return 0;
+}

@@ -1,0 +1,507 @@
+// Pooling, GAP->dropout->FC head, softmax / cross-entropy, Adam/SGD, layout conversion.  HBM-bound kernels:
+// NHWC bf16, one 16-byte chunk (8 channels) per lane, consecutive lanes on consecutive chunks.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct PoolArgs {
+    int H, W, C, ldx, R, S, sh, sw, ph, pw, P, Q, ldy;
+    int64_t total;   // work items
+    int cpr;
+};
+
+PoolArgs make_pool(const ifcbk_pool_desc* d, bool bwd) {
+    PoolArgs a;
+    a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx; a.R = d->R; a.S = d->S;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
+    a.cpr = d->C / 8;
+    a.total = (int64_t)d->N * (bwd ? (int64_t)d->H * d->W : (int64_t)d->P * d->Q) * a.cpr;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* arg, PoolArgs a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int c = (int)(i % a.cpr) * 8;
+    int64_t pix = i / a.cpr;
+    int q = (int)(pix % a.Q);
+    int64_t t2 = pix / a.Q;
+    int p = (int)(t2 % a.P);
+    int64_t n = t2 / a.P;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    bool first = true;
+    for (int r = 0; r < a.R; ++r) {
+        int h = p * a.sh - a.ph + r;
+        if (h < 0 || h >= a.H) continue;
+        for (int s = 0; s < a.S; ++s) {
+            int w = q * a.sw - a.pw + s;
+            if (w < 0 || w >= a.W) continue;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((n * a.H + h) * a.W + w) * a.ldx + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (first || f[j] > best[j] || f[j] != f[j]) { best[j] = f[j]; bi[j] = r * a.S + s; }
+            first = false;
+        }
+    }
+    *reinterpret_cast<uint4*>(y + pix * a.ldy + c) = pack8(best);
+    if (arg) {
+        uint2 v;
+        v.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        v.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *reinterpret_cast<uint2*>(arg + pix * a.C + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* arg, bf16_t* dx, PoolArgs a,
+                                                           int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int c = (int)(i % a.cpr) * 8;
+    int64_t pix = i / a.cpr;
+    int w = (int)(pix % a.W);
+    int64_t t2 = pix / a.W;
+    int h = (int)(t2 % a.H);
+    int64_t n = t2 / a.H;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    int plo = h + a.ph - a.R + 1; plo = plo <= 0 ? 0 : (plo + a.sh - 1) / a.sh;
+    int phi = (h + a.ph) / a.sh; if (phi >= a.P) phi = a.P - 1;
+    int qlo = w + a.pw - a.S + 1; qlo = qlo <= 0 ? 0 : (qlo + a.sw - 1) / a.sw;
+    int qhi = (w + a.pw) / a.sw; if (qhi >= a.Q) qhi = a.Q - 1;
+    for (int p = plo; p <= phi; ++p)
+        for (int q = qlo; q <= qhi; ++q) {
+            int want = (h - (p * a.sh - a.ph)) * a.S + (w - (q * a.sw - a.pw));
+            int64_t opix = (n * a.P + p) * a.Q + q;
+            uint2 av = *reinterpret_cast<const uint2*>(arg + opix * a.C + c);
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(dy + opix * a.ldy + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int idx = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xff;
+                if (idx == want) g[j] += f[j];
+            }
+        }
+    bf16_t* dp = dx + pix * a.ldx + c;
+    if (accumulate) {
+        float o[8];
+        unpack8(*reinterpret_cast<const uint4*>(dp), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += o[j];
+    }
+    *reinterpret_cast<uint4*>(dp) = pack8(g);
+}
+
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* x, bf16_t* y, PoolArgs a) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int c = (int)(i % a.cpr) * 8;
+    int64_t pix = i / a.cpr;
+    int q = (int)(pix % a.Q);
+    int64_t t2 = pix / a.Q;
+    int p = (int)(t2 % a.P);
+    int64_t n = t2 / a.P;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int r = 0; r < a.R; ++r) {
+        int h = p * a.sh - a.ph + r;
+        if (h < 0 || h >= a.H) continue;
+        for (int s = 0; s < a.S; ++s) {
+            int w = q * a.sw - a.pw + s;
+            if (w < 0 || w >= a.W) continue;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((n * a.H + h) * a.W + w) * a.ldx + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+    }
+    const float inv = 1.f / (float)(a.R * a.S);     // count_include_pad=True
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= inv;
+    *reinterpret_cast<uint4*>(y + pix * a.ldy + c) = pack8(acc);
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* dy, bf16_t* dx, PoolArgs a, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int c = (int)(i % a.cpr) * 8;
+    int64_t pix = i / a.cpr;
+    int w = (int)(pix % a.W);
+    int64_t t2 = pix / a.W;
+    int h = (int)(t2 % a.H);
+    int64_t n = t2 / a.H;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    int plo = h + a.ph - a.R + 1; plo = plo <= 0 ? 0 : (plo + a.sh - 1) / a.sh;
+    int phi = (h + a.ph) / a.sh; if (phi >= a.P) phi = a.P - 1;
+    int qlo = w + a.pw - a.S + 1; qlo = qlo <= 0 ? 0 : (qlo + a.sw - 1) / a.sw;
+    int qhi = (w + a.pw) / a.sw; if (qhi >= a.Q) qhi = a.Q - 1;
+    for (int p = plo; p <= phi; ++p)
+        for (int q = qlo; q <= qhi; ++q) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(dy + ((n * a.P + p) * a.Q + q) * a.ldy + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += f[j];
+        }
+    const float inv = 1.f / (float)(a.R * a.S);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= inv;
+    bf16_t* dp = dx + pix * a.ldx + c;
+    if (accumulate) {
+        float o[8];
+        unpack8(*reinterpret_cast<const uint4*>(dp), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += o[j];
+    }
+    *reinterpret_cast<uint4*>(dp) = pack8(g);
+}
+
+int pool_check(ifcbk_ctx* ctx, const ifcbk_pool_desc* d) {
+    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || d->ldx % 8 || d->ldy % 8)
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: bad desc (bf16, channels %%8)");
+    if (d->R * d->S > 255) IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: window too large");
+    return 0;
+}
+
+// ---------------------------------------------------------------- head
+// feat[n][c] = mean_hw x[n,hw,c] * (mask ? mask*keep_scale : 1)
+__global__ __launch_bounds__(256) void gap_kernel(const bf16_t* x, int ldx, int HW, int C, int64_t total, const uint8_t* mask,
+                                                  float keep_scale, float* feat) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cpr = C / 8;
+    int c = (int)(i % cpr) * 8;
+    int64_t n = i / cpr;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int hw = 0; hw < HW; ++hw) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (n * HW + hw) * ldx + c), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j] * inv;
+        if (mask) v *= mask[n * C + c + j] ? keep_scale : 0.f;
+        feat[n * C + c + j] = v;
+    }
+}
+
+// logits[n][j] = feat[n] . W[j] + b[j]; one block per sample, feat row in LDS, one wave per class
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float* feat, const float* W, const float* b, float* logits,
+                                                     int C, int NC) {
+    extern __shared__ float sf[];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < C; c += 256) sf[c] = feat[(size_t)n * C + c];
+    __syncthreads();
+    for (int j = wave; j < NC; j += 4) {
+        const float* w = W + (size_t)j * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += sf[c] * w[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) logits[(size_t)n * NC + j] = s + b[j];
+    }
+}
+
+// dW[j][c] (+)= sum_n dl[n][j]*feat[n][c];   thread per (j,c)
+__global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* dl, const float* feat, float* dW, int N, int C, int NC,
+                                                       int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)NC * C) return;
+    int c = (int)(i % C), j = (int)(i / C);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dl[(size_t)n * NC + j] * feat[(size_t)n * C + c];
+    dW[i] = accumulate ? dW[i] + s : s;
+}
+__global__ void fc_bgrad_kernel(const float* dl, float* db, int N, int NC, int accumulate) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= NC) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dl[(size_t)n * NC + j];
+    db[j] = accumulate ? db[j] + s : s;
+}
+// dx[n,hw,c] = (sum_j dl[n][j] W[j][c]) * mask*scale / HW ; thread per (n, chunk of 8 channels)
+__global__ __launch_bounds__(256) void head_dx_kernel(const float* dl, const float* W, const uint8_t* mask, float keep_scale,
+                                                      bf16_t* dx, int lddx, int HW, int C, int NC, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cpr = C / 8;
+    int c = (int)(i % cpr) * 8;
+    int64_t n = i / cpr;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    for (int k = 0; k < NC; ++k) {
+        float d = dl[n * NC + k];
+        const float* w = W + (size_t)k * C + c;
+        float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
+        g[0] += d * w0.x; g[1] += d * w0.y; g[2] += d * w0.z; g[3] += d * w0.w;
+        g[4] += d * w1.x; g[5] += d * w1.y; g[6] += d * w1.z; g[7] += d * w1.w;
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = g[j] * inv;
+        if (mask) v *= mask[n * C + c + j] ? keep_scale : 0.f;
+        g[j] = v;
+    }
+    uint4 pk = pack8(g);
+    for (int hw = 0; hw < HW; ++hw) *reinterpret_cast<uint4*>(dx + (n * HW + hw) * lddx + c) = pk;
+}
+
+// counter-based Bernoulli mask (splitmix64 of seed, offset+i)
+__global__ void dropout_mask_kernel(uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset + (uint64_t)i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    mask[i] = u >= p ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- loss (single block: deterministic mean)
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits, const int64_t* target, int N, int NC,
+                                                           float weight, float* loss_out, int loss_acc, float* dlogits) {
+    __shared__ float sl[256];
+    float local = 0.f;
+    const float invN = 1.f / (float)N;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* l = logits + (size_t)n * NC;
+        float mx = -INFINITY;
+        for (int j = 0; j < NC; ++j) mx = fmaxf(mx, l[j]);
+        float s = 0.f;
+        for (int j = 0; j < NC; ++j) s += expf(l[j] - mx);
+        float lse = mx + logf(s);
+        int tg = (int)target[n];
+        local += lse - l[tg];
+        if (dlogits) {
+            float* d = dlogits + (size_t)n * NC;
+            float is = 1.f / s;
+            for (int j = 0; j < NC; ++j) d[j] = weight * invN * (expf(l[j] - mx) * is - (j == tg ? 1.f : 0.f));
+        }
+    }
+    sl[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < 256; ++i) s += sl[i];
+        s = s * invN * weight;
+        loss_out[0] = loss_acc ? loss_out[0] + s : s;
+    }
+}
+__global__ void softmax_kernel(const float* logits, int N, int NC, float* probs) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* l = logits + (size_t)n * NC;
+    float mx = -INFINITY;
+    for (int j = 0; j < NC; ++j) mx = fmaxf(mx, l[j]);
+    float s = 0.f;
+    for (int j = 0; j < NC; ++j) s += expf(l[j] - mx);
+    float is = 1.f / s;
+    for (int j = 0; j < NC; ++j) probs[(size_t)n * NC + j] = expf(l[j] - mx) * is;
+}
+
+// ---------------------------------------------------------------- optimizers (flat)
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float sbc2,
+                                                   float gscale) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 pp = *reinterpret_cast<float4*>(p + i), gg = *reinterpret_cast<const float4*>(g + i);
+        float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        float* P = &pp.x; float* G = &gg.x; float* Mm = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = G[j] * gscale + wd * P[j];
+            Mm[j] = b1 * Mm[j] + (1.f - b1) * gr;
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+            float denom = sqrtf(V[j]) / sbc2 + eps;
+            P[j] -= (lr / bc1) * (Mm[j] / denom);
+        }
+        *reinterpret_cast<float4*>(p + i) = pp;
+        *reinterpret_cast<float4*>(m + i) = mm;
+        *reinterpret_cast<float4*>(v + i) = vv;
+    } else {
+        for (int64_t k = i; k < n; ++k) {
+            float gr = g[k] * gscale + wd * p[k];
+            m[k] = b1 * m[k] + (1.f - b1) * gr;
+            v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+            float denom = sqrtf(v[k]) / sbc2 + eps;
+            p[k] -= (lr / bc1) * (m[k] / denom);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* mom, int64_t n, float lr, float mu,
+                                                  float wd, float gscale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gr = g[i] * gscale + wd * p[i];
+    if (mom) {
+        float b = mu * mom[i] + gr;
+        mom[i] = b;
+        gr = b;
+    }
+    p[i] -= lr * gr;
+}
+
+// ---------------------------------------------------------------- layout
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int C, int64_t HW, int64_t total, int Cpad,
+                                                           float s0, float s1, float s2, float t0, float t1, float t2,
+                                                           bf16_t* y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index n*HW + hw
+    if (i >= total) return;
+    int64_t n = i / HW, hw = i - n * HW;
+    const float* src = x + n * C * HW + hw;
+    float sc[3] = {s0, s1, s2}, sh[3] = {t0, t1, t2};
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c0 + j;
+            float v = c < C ? src[c * HW] : 0.f;
+            if (c < 3 && c < C) v = v * sc[c] + sh[c];
+            f[j] = v;
+        }
+        *reinterpret_cast<uint4*>(y + i * Cpad + c0) = pack8(f);
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int C, int64_t HW, int64_t total, int ldx,
+                                                           float* y) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n*C*HW, hw fastest
+    if (i >= total) return;
+    int64_t hw = i % HW;
+    int64_t nc = i / HW;
+    int c = (int)(nc % C);
+    int64_t n = nc / C;
+    y[i] = bf2f(x[(n * HW + hw) * ldx + c]);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ifcbk_maxpool_fwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, void* y, uint8_t* argmax, void* stream) {
+    if (int e = pool_check(ctx, d)) return e;
+    PoolArgs a = make_pool(d, false);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, argmax, a);
+    IFCBK_LAUNCH_CHECK(ctx, "maxpool_fwd");
+    return 0;
+}
+extern "C" int ifcbk_maxpool_bwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* dy, const uint8_t* argmax, void* dx,
+                                 int accumulate, void* stream) {
+    if (int e = pool_check(ctx, d)) return e;
+    PoolArgs a = make_pool(d, true);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, argmax, (bf16_t*)dx, a, accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "maxpool_bwd");
+    return 0;
+}
+extern "C" int ifcbk_avgpool_fwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, void* y, void* stream) {
+    if (int e = pool_check(ctx, d)) return e;
+    PoolArgs a = make_pool(d, false);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, a);
+    IFCBK_LAUNCH_CHECK(ctx, "avgpool_fwd");
+    return 0;
+}
+extern "C" int ifcbk_avgpool_bwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* dy, void* dx, int accumulate, void* stream) {
+    if (int e = pool_check(ctx, d)) return e;
+    PoolArgs a = make_pool(d, true);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, a, accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "avgpool_bwd");
+    return 0;
+}
+
+extern "C" int ifcbk_head_fwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const void* x, const uint8_t* mask, const float* W,
+                              const float* b, float* feat, float* logits, void* stream) {
+    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || d->ldx % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: bad desc");
+    if ((size_t)d->C * 4 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
+    int64_t total = (int64_t)d->N * (d->C / 8);
+    hipLaunchKernelGGL(gap_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
+    IFCBK_LAUNCH_CHECK(ctx, "gap");
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(d->N), dim3(256), d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->C, d->NC);
+    IFCBK_LAUNCH_CHECK(ctx, "fc_fwd");
+    return 0;
+}
+extern "C" int ifcbk_head_bwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const float* dlogits, const float* feat,
+                              const uint8_t* mask, const float* W, float* dW, float* db, void* dx, int lddx,
+                              int param_accumulate, void* stream) {
+    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || lddx % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: bad desc");
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((int64_t)d->NC * d->C, 256)), dim3(256), 0, ST, dlogits, feat, dW, d->N, d->C, d->NC, param_accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "fc_wgrad");
+    hipLaunchKernelGGL(fc_bgrad_kernel, dim3(cdiv(d->NC, 64)), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "fc_bgrad");
+    if (dx) {
+        int64_t total = (int64_t)d->N * (d->C / 8);
+        hipLaunchKernelGGL(head_dx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, dlogits, W, mask, d->keep_scale, (bf16_t*)dx, lddx, d->HW, d->C, d->NC, total);
+        IFCBK_LAUNCH_CHECK(ctx, "head_dx");
+    }
+    return 0;
+}
+extern "C" int ifcbk_dropout_mask(ifcbk_ctx* ctx, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, mask, n, p, seed, offset);
+    IFCBK_LAUNCH_CHECK(ctx, "dropout_mask");
+    return 0;
+}
+
+extern "C" int ifcbk_softmax_xent(ifcbk_ctx* ctx, const float* logits, const int64_t* target, int N, int NC, float weight,
+                                  float* loss_out, int loss_accumulate, float* dlogits, void* stream) {
+    if (N <= 0 || NC <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "softmax_xent: empty");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, ST, logits, target, N, NC, weight, loss_out, loss_accumulate, dlogits);
+    IFCBK_LAUNCH_CHECK(ctx, "softmax_xent");
+    return 0;
+}
+extern "C" int ifcbk_softmax(ifcbk_ctx* ctx, const float* logits, int N, int NC, float* probs, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(N, 64)), dim3(64), 0, ST, logits, N, NC, probs);
+    IFCBK_LAUNCH_CHECK(ctx, "softmax");
+    return 0;
+}
+
+extern "C" int ifcbk_adam_flat(ifcbk_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (step < 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "adam: step must be >= 1");
+    float bc1 = 1.f - powf(beta1, (float)step);
+    float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(cdiv(cdiv(n, 4), 256)), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, sbc2, grad_scale);
+    IFCBK_LAUNCH_CHECK(ctx, "adam");
+    return 0;
+}
+extern "C" int ifcbk_sgd_flat(ifcbk_ctx* ctx, float* p, const float* g, float* mom, int64_t n, float lr, float momentum,
+                              float weight_decay, float grad_scale, void* stream) {
+    hipLaunchKernelGGL(sgd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST, p, g, mom, n, lr, momentum, weight_decay, grad_scale);
+    IFCBK_LAUNCH_CHECK(ctx, "sgd");
+    return 0;
+}
+
+extern "C" int ifcbk_nchw_to_nhwc(ifcbk_ctx* ctx, const float* x, int N, int C, int H, int W, int Cpad, int dtype,
+                                  const float* scale3, const float* shift3, void* y, void* stream) {
+    if (dtype != IFCBK_BF16 || Cpad % 8 || C > Cpad) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nchw_to_nhwc: bad args");
+    int64_t total = (int64_t)N * H * W;
+    float s[3] = {1, 1, 1}, t[3] = {0, 0, 0};
+    if (scale3) for (int i = 0; i < 3; ++i) s[i] = scale3[i];
+    if (shift3) for (int i = 0; i < 3; ++i) t[i] = shift3[i];
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, x, C, (int64_t)H * W, total, Cpad, s[0], s[1], s[2], t[0], t[1], t[2], (bf16_t*)y);
+    IFCBK_LAUNCH_CHECK(ctx, "nchw_to_nhwc");
+    return 0;
+}
+extern "C" int ifcbk_nhwc_to_nchw_f32(ifcbk_ctx* ctx, const void* x, int N, int C, int H, int W, int ldx, int dtype, float* y,
+                                      void* stream) {
+    if (dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nhwc_to_nchw: bad args");
+    int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, C, (int64_t)H * W, total, ldx, y);
+    IFCBK_LAUNCH_CHECK(ctx, "nhwc_to_nchw");
+    return 0;
+}

@@ -1,0 +1,213 @@
+/* libifcbk -- C-ABI of the MI355X (gfx950) kernels behind the ifcb_classifier train/infer hot path.
+ *
+ * The reference (WHOIGit/ifcb_classifier v0.3.1) has NO FFI: its hot path is Python calling
+ * torch/torchvision/PIL.  Each entry point below therefore cites the reference call site whose
+ * third-party primitive it replaces (file:line under /root/reference); INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers + explicit dims; the caller owns every buffer.
+ *   - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*); no host
+ *     sync, no allocation in steady state (hipGraph-capturable) once ifcbk_ctx_reserve has been called.
+ *   - return 0 on success, negative IFCBK_E* on error; text via ifcbk_last_error(); no C++ exception
+ *     crosses the ABI.
+ *   - a ctx is thread-compatible (one caller at a time), one per (process, GPU).
+ *   - activations are NHWC; `ld*` is the element stride between consecutive pixels so a tensor may be a
+ *     channel slice of a wider (concat) buffer.  Channel counts, ld* and slice offsets are multiples of 8.
+ *   - dtype: IFCBK_BF16 (2-byte storage, fp32 accumulate) is implemented; IFCBK_F32 is reserved.
+ */
+#ifndef IFCBK_H
+#define IFCBK_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFCBK_OK          0
+#define IFCBK_EINVAL     -1   /* bad descriptor / unsupported shape */
+#define IFCBK_EHIP       -2   /* HIP runtime error */
+#define IFCBK_ENOMEM     -3   /* workspace too small: call ifcbk_ctx_reserve outside capture */
+#define IFCBK_EUNSUPPORTED -4
+
+#define IFCBK_BF16 0
+#define IFCBK_F32  1
+
+typedef struct ifcbk_ctx ifcbk_ctx;
+
+const char* ifcbk_version(void);
+int  ifcbk_ctx_create(int device, ifcbk_ctx** out);
+int  ifcbk_ctx_destroy(ifcbk_ctx* ctx);
+/* grow the ctx-owned workspace (split-K slabs, resize coefficient tables) to >= bytes; syncs the device */
+int  ifcbk_ctx_reserve(ifcbk_ctx* ctx, size_t bytes);
+size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* ctx);
+const char* ifcbk_last_error(ifcbk_ctx* ctx);
+
+/* ------------------------------------------------------------------ convolution (implicit GEMM, MFMA)
+ * replaces aten::conv2d fwd/bwd reached from  neuston_models.py:66-68 (forward) and the autograd
+ * backward of [PL] automatic optimisation (neuston_models.py:63-64,81-86).                          */
+typedef struct {
+    int32_t N, H, W, C;      /* input  [N,H,W,C], C = channels the kernel reads (padded to %8)       */
+    int32_t ldx;             /* input pixel stride (elements)                                        */
+    int32_t K;               /* output channels                                                      */
+    int32_t R, S;            /* filter height, width                                                 */
+    int32_t stride_h, stride_w, pad_h, pad_w;
+    int32_t P, Q;            /* output height, width                                                 */
+    int32_t ldy;             /* output pixel stride (elements)                                       */
+    int32_t Cw;              /* channels of the MASTER weight/grad (3 for the stem conv, else == C)   */
+    int32_t dtype;
+} ifcbk_conv_desc;
+
+/* y[n,p,q,k] = sum_{r,s,c} x[n, p*sh-ph+r, q*sw-pw+s, c] * w[k,r,s,c]   (w: bf16 [K][R][S][C])
+ * bn_part (nullable): fp32 [ceil(N*P*Q/128)][2][K] per-M-block partial (sum, sum of squares) of the
+ * ROUNDED outputs, consumed by ifcbk_bn_finalize.                                                    */
+int ifcbk_conv2d_fwd(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y,
+                     float* bn_part, void* stream);
+/* dx[n,h,w,c] (+)= sum_{k,r,s} dy[n,p,q,k] * w[k,r,s,c];  wT = bf16 [C][R][S][K] with r,s FLIPPED
+ * (made by ifcbk_weight_pack).  accumulate!=0 adds into dx.                                          */
+int ifcbk_conv2d_dgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
+                       int accumulate, void* stream);
+/* dw[k,r,s,c] (+)= sum_{n,p,q} dy[n,p,q,k] * x[n, p*sh-ph+r, q*sw-pw+s, c];  dw fp32 [K][R][S][Cw];
+ * deterministic split-K through the ctx workspace.                                                  */
+int ifcbk_conv2d_wgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* dy, float* dw,
+                       int accumulate, void* stream);
+size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc*);
+int  ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc*);   /* rows of bn_part */
+/* master fp32 [K][R][S][Cw] -> bf16 shadow [K][R][S][C] (zero padded) and, if wT!=NULL, the flipped
+ * transposed dgrad shadow [C][R][S][K].                                                             */
+int ifcbk_weight_pack(ifcbk_ctx*, const ifcbk_conv_desc*, const float* w_master, void* w, void* wT,
+                      void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm (+ReLU, +residual)
+ * replaces aten::batch_norm / relu_ inside [TV] BasicConv2d and resnet blocks (neuston_models.py:66-68) */
+typedef struct {
+    int32_t M;               /* N*H*W pixels                                                          */
+    int32_t C;               /* channels                                                              */
+    int32_t ldx, ldy;        /* pixel strides of raw conv output / activated output                  */
+    int32_t relu;            /* 1: y = max(0, .)                                                      */
+    int32_t dtype;
+    float   eps, momentum;
+} ifcbk_bn_desc;
+
+/* train: part[mblocks][2][C] -> mean/invstd -> scale = g*invstd, shift = b - mean*scale;
+ * running_mean/var updated with momentum (unbiased var), as torch.nn.BatchNorm2d does.
+ * eval (part==NULL): scale/shift from the running statistics.                                       */
+int ifcbk_bn_finalize(ifcbk_ctx*, const ifcbk_bn_desc*, const float* part, int mblocks,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* y = act(x*scale + shift (+ residual)) */
+int ifcbk_bn_apply(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const float* scale,
+                   const float* shift, const void* residual, int ldr, void* y, void* stream);
+/* dz = dy * (y>0 if relu);  dgamma = sum dz*xhat;  dbeta = sum dz;
+ * dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M); if dres!=NULL: dres (+)= dz (residual branch).
+ * dy may alias dx.  part_ws: fp32 scratch of ifcbk_bn_bwd_workspace() bytes.                          */
+int ifcbk_bn_bwd(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* y, const void* dy, int lddy,
+                 const float* gamma, const float* mean, const float* invstd,
+                 void* dx, int lddx, void* dres, int lddres, int dres_accumulate,
+                 float* dgamma, float* dbeta, int param_accumulate, void* stream);
+
+/* ------------------------------------------------------------------ pooling
+ * replaces F.max_pool2d / F.avg_pool2d(count_include_pad=True) / adaptive_avg_pool2d in [TV] graphs  */
+typedef struct {
+    int32_t N, H, W, C, ldx;
+    int32_t R, S, stride_h, stride_w, pad_h, pad_w;
+    int32_t P, Q, ldy;
+    int32_t dtype;
+} ifcbk_pool_desc;
+int ifcbk_maxpool_fwd(ifcbk_ctx*, const ifcbk_pool_desc*, const void* x, void* y, uint8_t* argmax, void* stream);
+int ifcbk_maxpool_bwd(ifcbk_ctx*, const ifcbk_pool_desc*, const void* dy, const uint8_t* argmax, void* dx,
+                      int accumulate, void* stream);
+int ifcbk_avgpool_fwd(ifcbk_ctx*, const ifcbk_pool_desc*, const void* x, void* y, void* stream);
+int ifcbk_avgpool_bwd(ifcbk_ctx*, const ifcbk_pool_desc*, const void* dy, void* dx, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ head: GAP -> dropout -> FC
+ * replaces adaptive_avg_pool2d + dropout(0.5) + fc in [TV] Inception3.forward / ResNet.forward       */
+typedef struct {
+    int32_t N, HW, C, ldx;   /* input [N,HW,C]                                                        */
+    int32_t NC;              /* classes                                                               */
+    int32_t dtype;
+    float   keep_scale;      /* 1/(1-p) when mask!=NULL (2.0 for p=0.5)                               */
+} ifcbk_head_desc;
+/* feat[N][C] fp32 = mean_HW(x) * (mask? mask*keep_scale : 1); logits[N][NC] = feat @ W^T + b          */
+int ifcbk_head_fwd(ifcbk_ctx*, const ifcbk_head_desc*, const void* x, const uint8_t* mask,
+                   const float* W, const float* b, float* feat, float* logits, void* stream);
+/* dW (+)= dlogits^T feat; db (+)= sum dlogits; dx = (dlogits @ W) * mask*keep_scale / HW broadcast    */
+int ifcbk_head_bwd(ifcbk_ctx*, const ifcbk_head_desc*, const float* dlogits, const float* feat,
+                   const uint8_t* mask, const float* W, float* dW, float* db, void* dx, int lddx,
+                   int param_accumulate, void* stream);
+/* Bernoulli(keep = 1-p) mask bytes from a counter-based generator (seed, offset)                     */
+int ifcbk_dropout_mask(ifcbk_ctx*, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------ loss
+ * replaces nn.CrossEntropyLoss (mean) neuston_models.py:55,70-78 and softmax(dim=1) :99,:156          */
+/* loss_out[0] (+)= weight * mean_i CE(logits_i, target_i); dlogits = weight*(softmax - onehot)/N     */
+int ifcbk_softmax_xent(ifcbk_ctx*, const float* logits, const int64_t* target, int N, int NC, float weight,
+                       float* loss_out, int loss_accumulate, float* dlogits, void* stream);
+int ifcbk_softmax(ifcbk_ctx*, const float* logits, int N, int NC, float* probs, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * replaces torch.optim.Adam(lr=1e-3) neuston_models.py:63-64 (one flat launch instead of 292 loops)  */
+int ifcbk_adam_flat(ifcbk_ctx*, float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    void* stream);
+int ifcbk_sgd_flat(ifcbk_ctx*, float* p, const float* g, float* mom, int64_t n, float lr, float momentum,
+                   float weight_decay, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ input path
+ * replaces PIL convert('RGB') + transforms.Resize([S,S]) (PIL bilinear, antialiased, 8-bit fixed point)
+ * + ToTensor + Normalize: neuston_data.py:342-371, :456-464 (IfcbBinDataset.__getitem__)              */
+typedef struct {
+    int32_t n_img;           /* ROIs in the batch                                                     */
+    int32_t S;               /* output side (299 / 224)                                               */
+    int32_t in_channels;     /* 1 (grayscale ROI -> 3 identical channels) or 3 (interleaved RGB)      */
+    int32_t out_channels;    /* padded channel count of the NHWC output (8)                            */
+    int32_t flip_bits_valid; /* !=0: flips[i] bit0 = vertical flip ('x'), bit1 = horizontal ('y')     */
+    int32_t dtype;
+    float   mean[3], std[3]; /* Normalize; std = 1, mean = 0 for none                                 */
+    float   tin_scale[3], tin_shift[3]; /* [TV] transform_input affine (1,0 when off)                 */
+} ifcbk_roi_desc;
+/* pixels: concatenated u8 ROIs; offs[i] byte offset, hs[i]/ws[i] dims; out: [n_img,S,S,out_channels]  */
+int ifcbk_roi_preprocess(ifcbk_ctx*, const ifcbk_roi_desc*, const uint8_t* pixels, const int64_t* offs,
+                         const int32_t* hs, const int32_t* ws, const uint8_t* flips, int max_h, int max_w,
+                         void* out, uint8_t* out_u8 /*nullable: resized u8 [n,S,S,in_channels]*/, void* stream);
+size_t ifcbk_roi_preprocess_workspace(const ifcbk_roi_desc*, int max_h, int max_w);
+/* fp32 NCHW [N,3,H,W] -> NHWC [N,H,W,Cpad] (zero padded), optional per-channel affine (transform_input) */
+int ifcbk_nchw_to_nhwc(ifcbk_ctx*, const float* x, int N, int C, int H, int W, int Cpad, int dtype,
+                       const float* scale3, const float* shift3, void* y, void* stream);
+int ifcbk_nhwc_to_nchw_f32(ifcbk_ctx*, const void* x, int N, int C, int H, int W, int ldx, int dtype,
+                           float* y, void* stream);
+
+/* ------------------------------------------------------------------ program runner
+ * One call launches a whole forward / backward / update list: the host builds the op table once
+ * (static graph), so the per-step host cost is one FFI crossing.                                     */
+enum {
+    IFCBK_OP_CONV_FWD = 1, IFCBK_OP_CONV_DGRAD, IFCBK_OP_CONV_WGRAD, IFCBK_OP_WEIGHT_PACK,
+    IFCBK_OP_BN_FINALIZE, IFCBK_OP_BN_APPLY, IFCBK_OP_BN_BWD,
+    IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
+    IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
+    IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK
+};
+typedef struct {
+    int32_t kind;
+    int32_t flags;           /* accumulate etc. (per kind)                                            */
+    void*   p[12];           /* pointer operands in the order of the typed entry point               */
+    int64_t i[4];            /* scalar ints (per kind)                                                */
+    float   f[8];            /* scalar floats (per kind)                                              */
+    union {
+        ifcbk_conv_desc conv;
+        ifcbk_bn_desc   bn;
+        ifcbk_pool_desc pool;
+        ifcbk_head_desc head;
+    } u;
+} ifcbk_op;
+/* op_ms (nullable, host array of n floats): when given, every op is bracketed by HIP events on
+ * `stream`, the stream is synchronised at the end and per-op milliseconds are returned.             */
+int ifcbk_run_program(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, float* op_ms);
+/* algorithmic work of one op: flops (MAC*2 of conv/FC only) and minimum HBM bytes                   */
+int ifcbk_op_cost(const ifcbk_op* op, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

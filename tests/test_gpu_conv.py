@@ -1,0 +1,145 @@
+"""HIP implicit-GEMM conv fwd / dgrad / wgrad through the C-ABI vs torch-CPU F.conv2d (the reference's
+arithmetic: aten::conv2d reached from neuston_models.py:66-68) on bf16-representable inputs."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def nhwc(x, cpad=None):
+    """fp32 NCHW cpu -> bf16 NHWC cuda (channel padded)"""
+    n, c, h, w = x.shape
+    cp = cpad or c
+    out = torch.zeros(n, h, w, cp, dtype=torch.bfloat16)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out.cuda()
+
+
+def from_nhwc(y, c=None):
+    y = y.float().cpu()
+    if c is not None:
+        y = y[..., :c]
+    return y.permute(0, 3, 1, 2).contiguous()
+
+
+CASES = [
+    # N, C, H, W, K, R, S, sh, sw, ph, pw
+    (2, 32, 9, 9, 32, 3, 3, 1, 1, 0, 0),
+    (2, 16, 8, 8, 48, 1, 1, 1, 1, 0, 0),
+    (3, 64, 12, 12, 96, 3, 3, 1, 1, 1, 1),
+    (2, 48, 10, 10, 64, 5, 5, 1, 1, 2, 2),
+    (2, 128, 9, 9, 128, 1, 7, 1, 1, 0, 3),
+    (2, 128, 9, 9, 192, 7, 1, 1, 1, 3, 0),
+    (2, 96, 11, 11, 96, 3, 3, 2, 2, 0, 0),
+    (1, 288, 9, 9, 384, 3, 3, 2, 2, 0, 0),
+    (2, 80, 15, 15, 192, 3, 3, 1, 1, 0, 0),
+    (2, 8, 31, 31, 32, 3, 3, 2, 2, 0, 0),          # stem (C padded 3->8)
+    (1, 768, 5, 5, 160, 1, 1, 1, 1, 0, 0),
+    (2, 448, 8, 8, 384, 3, 3, 1, 1, 1, 1),
+    (1, 64, 16, 16, 64, 7, 7, 2, 2, 3, 3),         # resnet stem-like
+    (1, 64, 8, 8, 128, 1, 1, 2, 2, 0, 0),          # resnet downsample
+    (1, 128, 5, 5, 768, 5, 5, 1, 1, 0, 0),         # aux conv1
+    (5, 2048, 8, 8, 320, 1, 1, 1, 1, 0, 0),
+]
+
+
+def _desc(lib, N, Cc, H, W, K, R, S, sh, sw, ph, pw, ldx=None, ldy=None, Cw=None):
+    from ifcb_classifier_amd._lib import ConvDesc
+    P = (H + 2 * ph - R) // sh + 1
+    Q = (W + 2 * pw - S) // sw + 1
+    return ConvDesc(N, H, W, Cc, ldx or Cc, K, R, S, sh, sw, ph, pw, P, Q, ldy or K, Cw or Cc, 0)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd_dgrad_wgrad(ctx, case):
+    from ifcb_classifier_amd import _lib
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = _bf(torch.randn(N, Cc, H, W, generator=g))
+    w = _bf(torch.randn(K, Cc, R, S, generator=g) * (1.0 / (Cc * R * S) ** 0.5))
+    d = _desc(_lib, *case)
+    P, Q = d.P, d.Q
+    dy = _bf(torch.randn(N, K, P, Q, generator=g))
+    # oracle (torch CPU fp32)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, (sh, sw), (ph, pw))
+    yr.backward(dy)
+    st = _lib.cur_stream()
+    # ---- weight pack from the fp32 master (KRSC)
+    wm = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wk = torch.empty(K, R, S, Cc, dtype=torch.bfloat16, device='cuda')
+    wT = torch.empty(Cc, R, S, K, dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_weight_pack', C.byref(d), _lib.ptr(wm), _lib.ptr(wk), _lib.ptr(wT), st)
+    assert torch.equal(wk.float().cpu(), w.permute(0, 2, 3, 1))
+    # ---- forward (+ BN partial sums)
+    xd = nhwc(x)
+    y = torch.full((N, P, Q, K), float('nan'), dtype=torch.bfloat16, device='cuda')
+    mb = ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
+    part = torch.full((mb, 2, K), float('nan'), dtype=torch.float32, device='cuda')
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), _lib.ptr(xd), _lib.ptr(wk), _lib.ptr(y), _lib.ptr(part), st)
+    torch.cuda.synchronize()
+    yh = from_nhwc(y)
+    ref = yr.detach()
+    tol = 1e-2 * ref.abs().max().item() + 1e-6       # bf16 output rounding (2^-8 rel) dominates
+    assert (yh - _bf(ref)).abs().max().item() <= tol * 0.5, (yh - _bf(ref)).abs().max().item()
+    # statistics are those of the ROUNDED outputs, exactly
+    s1 = part[:, 0].sum(0).cpu()
+    s2 = part[:, 1].sum(0).cpu()
+    assert torch.allclose(s1, yh.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(s2, (yh * yh).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    # ---- dgrad
+    dyd = nhwc(dy)
+    dx = torch.full((N, H, W, Cc), float('nan'), dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_conv2d_dgrad', C.byref(d), _lib.ptr(dyd), _lib.ptr(wT), _lib.ptr(dx), 0, st)
+    torch.cuda.synchronize()
+    dxh = from_nhwc(dx)
+    rdx = xr.grad
+    assert (dxh - _bf(rdx)).abs().max().item() <= 0.5e-2 * rdx.abs().max().item() + 1e-6
+    # accumulate: second call doubles it
+    ctx.call('ifcbk_conv2d_dgrad', C.byref(d), _lib.ptr(dyd), _lib.ptr(wT), _lib.ptr(dx), 1, st)
+    torch.cuda.synchronize()
+    assert (from_nhwc(dx) - 2 * _bf(rdx)).abs().max().item() <= 2e-2 * rdx.abs().max().item() + 1e-6
+    # ---- wgrad (fp32 KRSC)
+    dw = torch.full((K, R, S, Cc), float('nan'), dtype=torch.float32, device='cuda')
+    ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
+    ctx.call('ifcbk_conv2d_wgrad', C.byref(d), _lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw), 0, st)
+    torch.cuda.synchronize()
+    rdw = wr.grad.permute(0, 2, 3, 1)
+    err = (dw.cpu() - rdw).abs().max().item()
+    assert err <= 2e-5 * max(1.0, rdw.abs().max().item()) * (N * P * Q) ** 0.5, err
+
+
+def test_conv_channel_slices(ctx):
+    """output written into a channel slice of a wider concat buffer; input read from a slice."""
+    from ifcb_classifier_amd import _lib
+    N, Cc, H, W, K = 2, 32, 7, 7, 64
+    g = torch.Generator().manual_seed(5)
+    xfull = _bf(torch.randn(N, 96, H, W, generator=g))
+    w = _bf(torch.randn(K, Cc, 1, 1, generator=g) * 0.2)
+    d = _desc(_lib, N, Cc, H, W, K, 1, 1, 1, 1, 0, 0, ldx=96, ldy=160)
+    xd = nhwc(xfull)
+    wk = w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    y = torch.zeros(N, H, W, 160, dtype=torch.bfloat16, device='cuda')
+    st = _lib.cur_stream()
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), C.c_void_p(xd.data_ptr() + 2 * 40), _lib.ptr(wk),
+             C.c_void_p(y.data_ptr() + 2 * 64), None, st)
+    torch.cuda.synchronize()
+    ref = F.conv2d(xfull[:, 40:72], w)
+    yh = from_nhwc(y)
+    assert (yh[:, 64:128] - _bf(ref)).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    assert yh[:, :64].abs().max().item() == 0 and yh[:, 128:].abs().max().item() == 0
+
+
+def test_conv_rejects_bad_desc(ctx):
+    from ifcb_classifier_amd import _lib
+    d = _desc(_lib, 1, 12, 8, 8, 16, 3, 3, 1, 1, 0, 0)      # C not a multiple of 8
+    with pytest.raises(RuntimeError, match='multiples of 8'):
+        ctx.call('ifcbk_conv2d_fwd', C.byref(d), None, None, None, None, None)
