@@ -1,0 +1,501 @@
+"""Plan/executor for one backbone on one GPU: owns the flat parameter / gradient / optimizer-state buffers,
+the NHWC activation and gradient buffers, and the op tables that ``ifcbk_run_program`` launches.
+
+No autograd, no tracing: the graph is static (``graph.py``), so forward, backward and update are three
+pre-built op tables; one FFI crossing launches a whole step.  PyTorch is used only for device memory and
+streams.  The HIP library is mandatory -- there is no CPU fallback in this module.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
+
+
+def _vp(t, byte_off=0):
+    return None if t is None else C.c_void_p(t.data_ptr() + byte_off)
+
+
+class OpList:
+    def __init__(self):
+        self.ops = []
+        self.tags = []
+
+    def add(self, kind, tag, p=(), i=(), f=(), flags=0, conv=None, bn=None, pool=None, head=None):
+        o = Op()
+        o.kind, o.flags = kind, flags
+        for k, v in enumerate(p):
+            o.p[k] = v if (v is None or isinstance(v, int)) else v.value
+        for k, v in enumerate(i):
+            o.i[k] = int(v)
+        for k, v in enumerate(f):
+            o.f[k] = float(v)
+        if conv is not None:
+            o.u.conv = conv
+        elif bn is not None:
+            o.u.bn = bn
+        elif pool is not None:
+            o.u.pool = pool
+        elif head is not None:
+            o.u.head = head
+        self.ops.append(o)
+        self.tags.append(tag)
+        return o
+
+    def extend(self, other):
+        self.ops.extend(other.ops)
+        self.tags.extend(other.tags)
+
+    def freeze(self):
+        arr = (Op * len(self.ops))(*self.ops)
+        return arr
+
+
+class Program:
+    def __init__(self, oplist):
+        self.tags = list(oplist.tags)
+        self.n = len(oplist.ops)
+        self.arr = oplist.freeze()
+
+    def find(self, kind):
+        return [k for k in range(self.n) if self.arr[k].kind == kind]
+
+
+class Engine:
+    """Device state of one model replica."""
+
+    def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not torch.cuda.is_available():
+            raise RuntimeError('ifcb_classifier_amd needs a HIP device (MI355X); none is visible and there is no CPU path')
+        self.net = net
+        self.dev = torch.device('cuda', device)
+        torch.cuda.set_device(self.dev)
+        self.ctx = _lib.Context(device)
+        self.max_batch = int(max_batch)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.packed = False
+        self.eval_stats_ready = False
+        self.dropout_seed = 0x1234
+        self.dropout_calls = 0
+        self.external_mask = None
+        self._plans = {}
+        self._alloc_params()
+        self._alloc_acts()
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self):
+        net, dev = self.net, self.dev
+        off = 0
+        self.poff = {}
+        for key, shape, kind, node in net.params:
+            n = int(math.prod(shape))
+            self.poff[key] = (off, n, shape, kind, node)
+            off += (n + 3) // 4 * 4           # keep every tensor 16-byte aligned
+        self.nparam_padded = off
+        self.P = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.V = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.pviews, self.gviews = {}, {}
+        for key, (o, n, shape, kind, node) in self.poff.items():
+            if kind == 'conv':
+                K, Cw, R, S = shape
+                self.pviews[key] = self.P[o:o + n].view(K, R, S, Cw).permute(0, 3, 1, 2)   # OIHW view of KRSC memory
+                self.gviews[key] = self.G[o:o + n].view(K, R, S, Cw).permute(0, 3, 1, 2)
+            else:
+                self.pviews[key] = self.P[o:o + n].view(shape)
+                self.gviews[key] = self.G[o:o + n].view(shape)
+        # BN running statistics
+        boff = 0
+        self.boff = {}
+        for key, shape, node in net.buffers:
+            self.boff[key] = (boff, shape[0])
+            boff += shape[0]
+        self.RB = torch.zeros(boff, dtype=torch.float32, device=dev)
+        self.bviews = {k: self.RB[o:o + n] for k, (o, n) in self.boff.items()}
+        for k, v in self.bviews.items():
+            if k.endswith('running_var'):
+                v.fill_(1.0)
+        convs = [n for n in net.nodes if getattr(n, 'kind', '') == 'conv']
+        self.convs = convs
+        self.nbt = torch.zeros(len(convs), dtype=torch.int64, device=dev)        # num_batches_tracked (all BNs)
+        # bf16 shadows + per-BN statistics
+        soff = 0
+        stoff = 0
+        for n in convs:
+            n.w_off = soff
+            soff += n.K * n.R * n.S * n.x.C
+            n.wT_off = soff
+            soff += n.K * n.R * n.S * n.x.C
+            n.st_off = stoff
+            stoff += 6 * n.K          # mean, invstd, scale, shift, eval_scale, eval_shift
+        self.Wsh = torch.zeros(soff, dtype=torch.bfloat16, device=dev)
+        self.stats = torch.zeros(stoff, dtype=torch.float32, device=dev)
+
+    def init_weights(self, seed=None):
+        """[TV] initialisation: truncated normal (inception) / kaiming fan_out (resnet); the replaced
+        ``fc`` heads use ``nn.Linear``'s default init (neuston_models.py:25-26,39)."""
+        g = torch.Generator(device='cpu')
+        if seed is not None:
+            g.manual_seed(int(seed))
+        else:
+            g.seed()
+        incep = self.net.name == 'inception_v3'
+        for key, (o, n, shape, kind, node) in self.poff.items():
+            v = self.pviews[key]
+            if kind == 'conv':
+                w = torch.empty(shape)
+                if incep:
+                    std = 0.01 if key.startswith('AuxLogits.conv1') else 0.1
+                    torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=g)
+                else:
+                    fan_out = shape[0] * shape[2] * shape[3]
+                    w.normal_(0, math.sqrt(2.0 / fan_out), generator=g)
+                v.copy_(w.to(self.dev))
+            elif kind == 'bn_w':
+                v.fill_(1.0)
+            elif kind == 'bn_b':
+                v.zero_()
+            elif kind == 'fc_w':
+                bound = 1.0 / math.sqrt(shape[1])
+                v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(self.dev))
+            elif kind == 'fc_b':
+                fan_in = self.poff[key[:-4] + 'weight'][2][1]
+                bound = 1.0 / math.sqrt(fan_in)
+                v.copy_(((torch.rand(shape, generator=g) * 2 - 1) * bound).to(self.dev))
+        self.params_changed()
+
+    def params_changed(self):
+        self.packed = False
+        self.eval_stats_ready = False
+
+    # ------------------------------------------------------------------ activations
+    def _alloc_acts(self):
+        net, dev, N = self.net, self.dev, self.max_batch
+        bf = torch.bfloat16
+        self.act = {}
+        self.grad = {}
+        for b in net.bufs:
+            self.act[b.id] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
+        need_grad = set()
+        for n in net.nodes:
+            if getattr(n, 'kind', '') == 'conv':
+                need_grad.add(n.y.buf.id)
+                if n.residual is not None:
+                    need_grad.add(n.residual.buf.id)
+            elif n.kind in ('max', 'avg'):
+                need_grad.add(n.y.buf.id)
+        need_grad.discard(net.input.id)
+        for bid in need_grad:
+            b = net.bufs[bid]
+            if b.name.endswith(':raw'):
+                continue
+            self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
+        max_raw = max(n.P * n.Q * n.K for n in self.convs)
+        self.draw = torch.zeros(N * max_raw, dtype=bf, device=dev)
+        mb = max(((N * n.P * n.Q + 127) // 128) * 2 * n.K for n in self.convs)
+        self.bn_part = torch.zeros(mb, dtype=torch.float32, device=dev)
+        self.argmax = {}
+        for k, n in enumerate(net.nodes):
+            if n.kind == 'max':
+                self.argmax[k] = torch.zeros(N, n.P, n.Q, n.x.C, dtype=torch.uint8, device=dev)
+        self.heads = [n for n in net.nodes if n.kind == 'head']
+        for h in self.heads:
+            h.feat = torch.zeros(N, h.C, dtype=torch.float32, device=dev)
+            h.logits = torch.zeros(N, h.NC, dtype=torch.float32, device=dev)
+            h.dlogits = torch.zeros(N, h.NC, dtype=torch.float32, device=dev)
+            h.mask = torch.ones(N, h.C, dtype=torch.uint8, device=dev) if h.dropout else None
+        self.probs = torch.zeros(N, net.NC, dtype=torch.float32, device=dev)
+        self.target = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        # workspace: wgrad split-K slabs / bn_bwd partials
+        ws = 1 << 20
+        for n in self.convs:
+            d = self._conv_desc(n, N)
+            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
+            M = N * n.P * n.Q
+            ws = max(ws, (((M + 1023) // 1024) * 2 * n.K + 2 * n.K) * 4)
+        self.ctx.reserve(ws)
+
+    def activation_bytes(self):
+        tot = sum(t.numel() * t.element_size() for t in self.act.values())
+        tot += sum(t.numel() * t.element_size() for t in self.grad.values())
+        return tot + self.draw.numel() * 2
+
+    # ------------------------------------------------------------------ descriptors
+    @staticmethod
+    def _conv_desc(n, N):
+        return ConvDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.K, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q,
+                        n.y.buf.C, n.Cw, _lib.BF16)
+
+    def _aptr(self, view, grad=False):
+        t = (self.grad if grad else self.act)[view.buf.id]
+        return _vp(t, 2 * view.coff)
+
+    def _pptr(self, key, which='P'):
+        o = self.poff[key][0]
+        return _vp(getattr(self, which), 4 * o)
+
+    def _stat(self, n, k):
+        return _vp(self.stats, 4 * (n.st_off + k * n.K))
+
+    # ------------------------------------------------------------------ programs
+    def plan(self, N):
+        if N > self.max_batch:
+            raise RuntimeError('batch %d exceeds the engine capacity %d' % (N, self.max_batch))
+        if N not in self._plans:
+            self._plans[N] = self._build(N)
+        return self._plans[N]
+
+    def _build(self, N):
+        net = self.net
+        fwd_t, fwd_e, bwd = OpList(), OpList(), OpList()
+        pack, evalprep = OpList(), OpList()
+        written = set()       # grad buffers already written in this backward pass
+
+        def acc_flag(buf):
+            a = 1 if buf.id in written else 0
+            written.add(buf.id)
+            return a
+
+        bwd_groups = []
+        for k, n in enumerate(net.nodes):
+            grp = OpList()
+            if n.kind == 'conv':
+                M = N * n.P * n.Q
+                d = self._conv_desc(n, N)
+                # forward conv writes the raw output (own buffer, ld = K)
+                dfw = ConvDesc.from_buffer_copy(d)
+                dfw.ldy = n.K
+                raw = _vp(self.act[n.raw.id])
+                wk = _vp(self.Wsh, 2 * n.w_off)
+                wT = _vp(self.Wsh, 2 * n.wT_off)
+                ckey, bkey = n.conv_key + '.weight', n.bn_key
+                mb = (M + 127) // 128
+                bnd = BnDesc(M, n.K, n.K, n.y.buf.C, 1 if n.relu else 0, _lib.BF16, n.eps, 0.1)
+                res = self._aptr(n.residual) if n.residual is not None else None
+                ldr = n.residual.buf.C if n.residual is not None else 0
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    if n.aux and not train:
+                        continue
+                    lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part) if train else None),
+                            conv=dfw)
+                    if train:
+                        lst.add(_lib.OP_BN_FINALIZE, n.name,
+                                p=(_vp(self.bn_part), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
+                                   _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
+                                   self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3)),
+                                i=(mb,), bn=bnd)
+                    lst.add(_lib.OP_BN_APPLY, n.name,
+                            p=(raw, self._stat(n, 2 if train else 4), self._stat(n, 3 if train else 5), res, self._aptr(n.y)),
+                            i=(ldr,), bn=bnd)
+                evalprep.add(_lib.OP_BN_FINALIZE, n.name,
+                             p=(None, self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
+                                _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
+                                None, None, self._stat(n, 4), self._stat(n, 5)), i=(0,), bn=bnd)
+                needs_dgrad = not n.x.buf.is_input
+                pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), conv=d)
+                # ---- backward of this node
+                draw = _vp(self.draw)
+                dres, lddres, dres_acc = None, 0, 0
+                # (flags resolved later, in reverse order) -> store a closure
+                bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad))
+            elif n.kind in ('max', 'avg'):
+                pd = PoolDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q, n.y.buf.C,
+                              _lib.BF16)
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    if n.aux and not train:
+                        continue
+                    if n.kind == 'max':
+                        lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd)
+                    else:
+                        lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd)
+                bwd_groups.append(('pool', n, pd, k))
+            elif n.kind == 'head':
+                hd = HeadDesc(N, n.HW, n.C, n.x.buf.C, n.NC, _lib.BF16, 2.0)
+                wkey, bkey = n.key + '.weight', n.key + '.bias'
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    if n.aux and not train:
+                        continue
+                    mask = _vp(n.mask) if (train and n.dropout) else None
+                    lst.add(_lib.OP_HEAD_FWD, n.name, p=(self._aptr(n.x), mask, self._pptr(wkey), self._pptr(bkey), _vp(n.feat), _vp(n.logits)), head=hd)
+                bwd_groups.append(('head', n, hd))
+
+        # backward in reverse node order, resolving first-writer / accumulate flags
+        for g in reversed(bwd_groups):
+            if g[0] == 'head':
+                _, n, hd = g
+                wkey, bkey = n.key + '.weight', n.key + '.bias'
+                assert n.x.is_full
+                acc = acc_flag(n.x.buf)
+                assert acc == 0, 'head must be the first writer of its input gradient'
+                bwd.add(_lib.OP_HEAD_BWD, n.name,
+                        p=(_vp(n.dlogits), _vp(n.feat), _vp(n.mask) if n.dropout else None, self._pptr(wkey),
+                           self._pptr(wkey, 'G'), self._pptr(bkey, 'G'), self._aptr(n.x, True)),
+                        i=(n.x.buf.C,), head=hd)
+            elif g[0] == 'pool':
+                _, n, pd, k = g
+                assert n.x.is_full
+                acc = acc_flag(n.x.buf)
+                if n.kind == 'max':
+                    bwd.add(_lib.OP_MAXPOOL_BWD, n.name, p=(self._aptr(n.y, True), _vp(self.argmax[k]), self._aptr(n.x, True)), flags=acc, pool=pd)
+                else:
+                    bwd.add(_lib.OP_AVGPOOL_BWD, n.name, p=(self._aptr(n.y, True), self._aptr(n.x, True)), flags=acc, pool=pd)
+            else:
+                _, n, d, bnd, draw, wT, needs_dgrad = g
+                ckey, bkey = n.conv_key + '.weight', n.bn_key
+                dres, lddres, dres_acc = None, 0, 0
+                if n.residual is not None:
+                    assert n.residual.is_full
+                    dres_acc = acc_flag(n.residual.buf)
+                    dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
+                bwd.add(_lib.OP_BN_BWD, n.name,
+                        p=(_vp(self.act[n.raw.id]), self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
+                           self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
+                           self._pptr(bkey + '.bias', 'G')),
+                        i=(n.y.buf.C, n.K, lddres), flags=dres_acc, bn=bnd)
+                dbw = ConvDesc.from_buffer_copy(d)
+                dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
+                bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw)
+                if needs_dgrad:
+                    assert n.x.is_full
+                    acc = acc_flag(n.x.buf)
+                    bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw)
+
+        class PlanObj:
+            pass
+        pl = PlanObj()
+        pl.N = N
+        pl.fwd_train, pl.fwd_eval, pl.bwd = Program(fwd_t), Program(fwd_e), Program(bwd)
+        pl.pack, pl.evalprep = Program(pack), Program(evalprep)
+        # loss ops: CE(main) + 0.4*CE(aux)   (neuston_models.py:70-78)
+        lossl = OpList()
+        main = [h for h in self.heads if not h.aux][0]
+        auxh = [h for h in self.heads if h.aux]
+        lossl.add(_lib.OP_SOFTMAX_XENT, 'loss', p=(_vp(main.logits), _vp(self.target), _vp(self.loss), _vp(main.dlogits)),
+                  i=(N, net.NC), f=(1.0,))
+        for h in auxh:
+            lossl.add(_lib.OP_SOFTMAX_XENT, 'loss_aux', p=(_vp(h.logits), _vp(self.target), _vp(self.loss), _vp(h.dlogits)),
+                      i=(N, net.NC), f=(0.4,), flags=1)
+        pl.loss = Program(lossl)
+        evl = OpList()
+        evl.add(_lib.OP_SOFTMAX_XENT, 'val_loss', p=(_vp(main.logits), _vp(self.target), _vp(self.loss), None), i=(N, net.NC), f=(1.0,))
+        pl.eval_loss = Program(evl)
+        sm = OpList()
+        sm.add(_lib.OP_SOFTMAX, 'softmax', p=(_vp(main.logits), _vp(self.probs)), i=(N, net.NC))
+        pl.softmax = Program(sm)
+        opt = OpList()
+        opt.add(_lib.OP_ADAM, 'adam', p=(_vp(self.P), _vp(self.G), _vp(self.M), _vp(self.V)),
+                i=(self.nparam_padded, 1), f=(self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0))
+        pl.adam = Program(opt)
+        # fused train step = fwd + loss + bwd + adam + pack
+        allops = OpList()
+        for prog_ops in (fwd_t, lossl, bwd, opt, pack):
+            allops.extend(prog_ops)
+        pl.step = Program(allops)
+        pl.step_adam_idx = pl.step.find(_lib.OP_ADAM)[0]
+        return pl
+
+    # ------------------------------------------------------------------ execution
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def run(self, prog, op_ms=None):
+        self.ctx.run_program(prog.arr, prog.n, self.stream(), op_ms)
+
+    def ensure_packed(self, pl):
+        if not self.packed:
+            self.run(pl.pack)
+            self.packed = True
+
+    def load_input_nchw(self, x):
+        """fp32 NCHW [N,3,S,S] (device) -> the plan's NHWC bf16 input buffer (+ [TV] transform_input)."""
+        N, Cc, H, W = x.shape
+        S = self.net.S
+        if Cc != 3 or H != S or W != S:
+            raise RuntimeError('expected input [N,3,%d,%d], got %s' % (S, S, tuple(x.shape)))
+        x = x.to(device=self.dev, dtype=torch.float32).contiguous()
+        sc = sh = None
+        if self.net.transform_input:
+            sc = (C.c_float * 3)(0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5)
+            sh = (C.c_float * 3)((0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5)
+        self.ctx.call('ifcbk_nchw_to_nhwc', _vp(x), N, 3, S, S, 8, _lib.BF16, sc, sh, _vp(self.act[self.net.input.id]),
+                      self.stream())
+        return N
+
+    def load_rois(self, pixels, offs, hs, ws, max_h, max_w, in_channels=1, flips=None, mean=None, std=None):
+        """ragged u8 ROIs (device tensors) -> input buffer via the PIL-exact resize kernel."""
+        n = hs.numel()
+        d = RoiDesc()
+        d.n_img, d.S, d.in_channels, d.out_channels = n, self.net.S, in_channels, 8
+        d.flip_bits_valid = 1 if flips is not None else 0
+        d.dtype = _lib.BF16
+        for k in range(3):
+            d.mean[k] = 0.0 if mean is None else float(mean[k])
+            d.std[k] = 1.0 if std is None else float(std[k])
+            d.tin_scale[k], d.tin_shift[k] = 1.0, 0.0
+        if self.net.transform_input:
+            for k, (s, m) in enumerate(((0.229, 0.485), (0.224, 0.456), (0.225, 0.406))):
+                d.tin_scale[k], d.tin_shift[k] = s / 0.5, (m - 0.5) / 0.5
+        need = self.ctx.lib.ifcbk_roi_preprocess_workspace(C.byref(d), int(max_h), int(max_w))
+        if need > self.ctx.lib.ifcbk_ctx_workspace_bytes(self.ctx.h):
+            self.ctx.reserve(need)
+        self.ctx.call('ifcbk_roi_preprocess', C.byref(d), _vp(pixels), _vp(offs), _vp(hs), _vp(ws), _vp(flips),
+                      int(max_h), int(max_w), _vp(self.act[self.net.input.id]), None, self.stream())
+        return n
+
+    def make_dropout_mask(self, N):
+        for h in self.heads:
+            if h.dropout:
+                if self.external_mask is not None:
+                    h.mask[:N].copy_(self.external_mask[:N].to(torch.uint8))
+                else:
+                    self.ctx.call('ifcbk_dropout_mask', _vp(h.mask), N * h.C, 0.5, self.dropout_seed,
+                                  self.dropout_calls * (1 << 24), self.stream())
+        self.dropout_calls += 1
+
+    def forward_train(self, N):
+        pl = self.plan(N)
+        self.ensure_packed(pl)
+        self.make_dropout_mask(N)
+        self.run(pl.fwd_train)
+        self.nbt += 1
+        self.eval_stats_ready = False
+        return pl
+
+    def forward_eval(self, N):
+        pl = self.plan(N)
+        self.ensure_packed(pl)
+        if not self.eval_stats_ready:
+            self.run(pl.evalprep)
+            self.eval_stats_ready = True
+        self.run(pl.fwd_eval)
+        return pl
+
+    def backward(self, N):
+        self.run(self.plan(N).bwd)
+
+    def adam_step(self, N):
+        pl = self.plan(N)
+        self.step_count += 1
+        pl.adam.arr[0].i[1] = self.step_count
+        self.run(pl.adam)
+        self.packed = False
+        self.eval_stats_ready = False
+
+    def train_step(self, N, op_ms=None):
+        """one fused launch list: fwd + CE(+0.4 aux) + bwd + Adam + weight repack; loss stays on device."""
+        pl = self.plan(N)
+        self.ensure_packed(pl)
+        self.make_dropout_mask(N)
+        self.step_count += 1
+        pl.step.arr[pl.step_adam_idx].i[1] = self.step_count
+        self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)
+        self.nbt += 1
+        self.loss_sum += self.loss
+        self.eval_stats_ready = False
+        return pl

@@ -1,0 +1,271 @@
+"""Drop-in twin of ``/root/reference/neuston_models.py``: ``get_namebrand_model`` (:22-45) and
+``NeustonModel`` (:48-190), with the torchvision backbone replaced by the MI355X engine.
+
+``get_namebrand_model`` returns an ``nn.Module`` honouring the reference's module contract: callable on
+fp32 NCHW ``[B,3,S,S]``; train mode returns ``InceptionOutputs(logits, aux_logits)`` for inception_v3 and a
+plain tensor otherwise; ``state_dict()`` keys/shapes are torchvision's (OIHW fp32 views of the engine's flat
+KRSC master buffer); ``parameters()`` in [TV] registration order; ``loss.backward()`` drives the HIP backward
+through one autograd node and leaves ``param.grad`` as views of the flat gradient buffer.
+"""
+import argparse
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import graph
+from .engine import Engine
+
+InceptionOutputs = namedtuple('InceptionOutputs', ['logits', 'aux_logits'])
+InceptionOutputs.__annotations__ = {'logits': torch.Tensor, 'aux_logits': torch.Tensor}
+
+
+class _NetFn(torch.autograd.Function):
+    """whole-network autograd node: forward already ran; backward runs the HIP backward program."""
+
+    @staticmethod
+    def forward(ctx, hook, module, N, *outs):
+        ctx.module, ctx.N = module, N
+        return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        m, N = ctx.module, ctx.N
+        eng = m.engine
+        for h, g in zip(m._train_heads, gouts):
+            if g is None:
+                h.dlogits[:N].zero_()
+            else:
+                h.dlogits[:N].copy_(g)
+        eng.backward(N)
+        for key, p in m._pmap.items():
+            gv = eng.gviews[key]
+            if p.grad is None:
+                p.grad = gv
+            elif p.grad.data_ptr() != gv.data_ptr():
+                p.grad.add_(gv)
+        return (None, None, None) + (None,) * len(gouts)
+
+
+class HipBackbone(nn.Module):
+    def __init__(self, net, device=0, max_batch=None):
+        super().__init__()
+        max_batch = max_batch or 32
+        object.__setattr__(self, 'engine', Engine(net, device, max_batch))
+        object.__setattr__(self, 'net', net)
+        eng = self.engine
+        pmap = {}
+        for key, shape, kind, node in net.params:
+            mod, leaf = self._submodule(key)
+            p = nn.Parameter(eng.pviews[key], requires_grad=True)
+            mod.register_parameter(leaf, p)
+            pmap[key] = p
+        object.__setattr__(self, '_pmap', pmap)
+        for k, (key, shape, node) in enumerate(net.buffers):
+            mod, leaf = self._submodule(key)
+            mod.register_buffer(leaf, eng.bviews[key])
+            if leaf == 'running_var':
+                mod.register_buffer('num_batches_tracked', eng.nbt[eng.convs.index(node)])
+        object.__setattr__(self, '_hook', torch.zeros(1, device=eng.dev, requires_grad=True))
+        object.__setattr__(self, '_train_heads', sorted(eng.heads, key=lambda h: h.aux))
+        self.num_classes = net.NC
+        eng.init_weights()
+
+    def _submodule(self, key):
+        parts = key.split('.')
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        return mod, parts[-1]
+
+    # parameters may be modified behind the engine's back (optimizer.step, load_state_dict)
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.engine.params_changed()
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict)
+        self.engine.params_changed()
+        return r
+
+    def set_dropout_mask(self, mask):
+        """parity hook: fix the Bernoulli keep-mask [B,2048] of the train-mode dropout (None = generate)."""
+        self.engine.external_mask = mask
+
+    def forward(self, x):
+        eng = self.engine
+        if x.shape[0] > eng.max_batch:
+            raise RuntimeError('batch %d > max_batch %d (construct with a larger max_batch)' % (x.shape[0], eng.max_batch))
+        N = eng.load_input_nchw(x)
+        if self.training:
+            if torch.is_grad_enabled():
+                eng.params_changed()          # an external optimizer may have stepped since the last call
+            eng.forward_train(N)
+            outs = [h.logits[:N] for h in self._train_heads]
+            if torch.is_grad_enabled():
+                outs = _NetFn.apply(self._hook, self, N, *outs)
+            else:
+                outs = [o.clone() for o in outs]
+            if self.net.has_aux:
+                return InceptionOutputs(outs[0], outs[1])
+            return outs[0]
+        eng.params_changed()
+        eng.forward_eval(N)
+        return self._train_heads[0].logits[:N].clone()
+
+
+def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None):
+    """``neuston_models.py:22-45``.  Backbones on the HIP path: inception_v3, resnet18/34/50/101/152.
+    ``pretrained=True`` cannot download ImageNet weights here (no torchvision / network): it switches on
+    inception's ``transform_input`` exactly as torchvision does and expects a ``load_state_dict`` to follow.
+    Names the reference accepts but this path does not implement raise ``NotImplementedError``; names the
+    reference rejects raise its ``KeyError("model unknown!")``."""
+    if model_name in ('alexnet', 'squeezenet') or model_name.startswith(('vgg', 'densenet')):
+        raise NotImplementedError('%s is accepted by the reference but not built on the MI355X path yet' % model_name)
+    net = graph.build(model_name, num_o_classes, pretrained)
+    return HipBackbone(net, device, max_batch)
+
+
+class NeustonModel(nn.Module):
+    """``neuston_models.py:48-180`` without Lightning: same hooks, same loss, same optimizer, same
+    aggregation.  ``training_step`` / ``validation_step`` / ``test_step`` accept the reference's batch tuples.
+    The fused fast path (``fit_batch``) runs forward+loss+backward+Adam as one HIP program."""
+
+    def __init__(self, hparams, device=0, max_batch=None):
+        super().__init__()
+        if isinstance(hparams, dict):
+            hparams = argparse.Namespace(**hparams)
+        self.hparams = hparams
+        self.criterion = nn.CrossEntropyLoss()
+        mb = max_batch or getattr(hparams, 'batch_size', None) or 32
+        self.model = get_namebrand_model(hparams.MODEL, len(hparams.classes), hparams.pretrained, device, mb)
+        self.best_val_loss = np.inf
+        self.best_epoch = 0
+        self.agg_train_loss = 0.0
+        self.current_epoch = 0
+        self.logged = {}
+
+    def configure_optimizers(self):
+        from torch.optim import Adam
+        return Adam(self.parameters(), lr=0.001)
+
+    def forward(self, inputs):
+        return self.model(inputs)
+
+    def loss(self, inputs, outputs):
+        if isinstance(outputs, tuple) and len(outputs) == 2:  # inception_v3
+            outputs, aux_outputs = outputs
+            loss1 = self.criterion(outputs, inputs)
+            loss2 = self.criterion(aux_outputs, inputs)
+            batch_loss = loss1 + 0.4 * loss2
+        else:
+            batch_loss = self.criterion(outputs, inputs)
+        return batch_loss
+
+    # TRAINING (reference hook: autograd through the HIP backward, any torch optimizer) #
+    def training_step(self, batch, batch_nb):
+        input_data, input_classes, input_src = batch
+        outputs = self.forward(input_data)
+        batch_loss = self.loss(input_classes.to(outputs[0].device if isinstance(outputs, tuple) else outputs.device), outputs)
+        self.agg_train_loss += batch_loss.item()
+        return dict(loss=batch_loss)
+
+    # TRAINING (fast path: one fused HIP program; loss accumulated on device, read once per epoch) #
+    def fit_batch(self, input_data, input_classes):
+        eng = self.model.engine
+        if torch.is_tensor(input_data):
+            N = eng.load_input_nchw(input_data)
+        else:
+            N = eng.load_rois(**input_data)
+        eng.target[:N].copy_(input_classes, non_blocking=True)
+        self.model.train()
+        eng.train_step(N)
+        return N
+
+    def epoch_train_loss(self):
+        eng = self.model.engine
+        v = float(eng.loss_sum.item())
+        eng.loss_sum.zero_()
+        return v
+
+    # Validation #
+    def validation_step(self, batch, batch_idx):
+        input_data, input_classes, input_src = batch
+        with torch.no_grad():
+            outputs = self.forward(input_data)
+            input_classes = input_classes.to(outputs.device)
+            val_batch_loss = self.loss(input_classes, outputs)
+            outputs = outputs.logits if isinstance(outputs, InceptionOutputs) else outputs
+            outputs = torch.softmax(outputs, dim=1)
+        return dict(val_batch_loss=val_batch_loss, val_outputs=outputs, val_input_classes=input_classes,
+                    val_input_srcs=input_src)
+
+    def validation_epoch_end(self, steps):
+        from sklearn import metrics
+        if self.current_epoch == 0:
+            self.best_val_loss = np.inf
+        validation_loss = torch.stack([batch['val_batch_loss'] for batch in steps]).sum()
+        if validation_loss.item() < self.best_val_loss:
+            self.best_val_loss = validation_loss.item()
+            self.best_epoch = self.current_epoch
+        outputs = torch.cat([batch['val_outputs'] for batch in steps], dim=0).detach().cpu().numpy()
+        output_classes = np.argmax(outputs, axis=1)
+        input_classes = torch.cat([batch['val_input_classes'] for batch in steps], dim=0).detach().cpu().numpy()
+        input_srcs = [item for sublist in [batch['val_input_srcs'] for batch in steps] for item in sublist]
+        f1_weighted = metrics.f1_score(input_classes, output_classes, average='weighted')
+        f1_macro = metrics.f1_score(input_classes, output_classes, average='macro')
+        eoe = 'Best Epoch: {}, train_loss: {:.3f}, val_loss: {:.3f}, val_f1_w={:02.1f}%, val_f1_m={:02.1f}%'
+        eoe = eoe.format(True if self.current_epoch == self.best_epoch else self.best_epoch + 1, self.agg_train_loss,
+                         validation_loss, 100 * f1_weighted, 100 * f1_macro)
+        print(eoe, flush=True, end='\n\n')
+        self.logged = dict(epoch=self.current_epoch, best=self.best_epoch == self.current_epoch,
+                           train_loss=self.agg_train_loss, val_loss=validation_loss.item(),
+                           input_classes=input_classes, output_classes=output_classes, input_srcs=input_srcs,
+                           outputs=outputs, f1_macro=f1_macro, f1_weighted=f1_weighted)
+        self.agg_train_loss = 0.0
+        return dict(hiddens=dict(outputs=outputs))
+
+    # RUNNING the model #
+    def test_step(self, batch, batch_idx, dataloader_idx=None):
+        input_data, input_srcs = batch
+        with torch.no_grad():
+            outputs = self.forward(input_data)
+            outputs = outputs.logits if isinstance(outputs, InceptionOutputs) else outputs
+            outputs = torch.softmax(outputs, dim=1)
+        return dict(test_outputs=outputs, test_srcs=input_srcs)
+
+    def test_epoch_end(self, steps, input_obj=None):
+        outputs = torch.cat([batch['test_outputs'] for batch in steps], dim=0).detach().cpu().numpy()
+        images = [item for batch in steps for item in batch['test_srcs']]
+        rr = self.RunResults(inputs=images, outputs=outputs, input_obj=input_obj)
+        self.logged = dict(RunResults=[rr])
+        return rr
+
+    class RunResults:
+        def __init__(self, inputs, outputs, input_obj, bin_pid=False):
+            self.inputs = inputs
+            self.outputs = outputs
+            self.input_obj = input_obj
+            self.type = 'Bin' if bin_pid else 'ImgDir'
+
+        def __repr__(self):
+            rep = '{}: {} ({} imgs)'.format(self.type, self.input_obj, len(self.inputs))
+            return repr(rep)
+
+    # checkpoints: the [PL] dict layout the reference reads back (neuston_net.py:173,443)
+    def checkpoint_dict(self, epoch=0, global_step=0):
+        hp = dict(vars(self.hparams))
+        return dict(epoch=epoch, global_step=global_step, pytorch_lightning_version='1.3.8',
+                    state_dict={k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                    hyper_parameters=hp)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, device=0, max_batch=None):
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        hp = dict(ckpt['hyper_parameters'])
+        obj = cls(hp, device=device, max_batch=max_batch)
+        obj.load_state_dict(ckpt['state_dict'])
+        return obj

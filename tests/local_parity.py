@@ -1,0 +1,81 @@
+"""Walk the HIP plan node by node after one forward+backward and check every node against the node-level
+CPU oracle (oracle/ops.py) on the HIP path's OWN inputs (teacher forcing).  Returns a dict of worst errors."""
+import torch
+
+from oracle import ops as O
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _nchw(t, view, N):
+    return t[:N, :, :, view.coff:view.coff + view.C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def check_plan(hip, N, mask=None, verbose=False):
+    eng = hip.engine
+    net = eng.net
+    act = lambda v: _nchw(eng.act[v.buf.id], v, N)
+    grd = lambda v: _nchw(eng.grad[v.buf.id], v, N)
+    P = {k: p.detach().cpu() for k, p in hip.named_parameters()}
+    G = {k: p.grad.detach().cpu() for k, p in hip.named_parameters()}
+    expected = {}      # buf id -> expected total gradient (NCHW fp32)
+    worst = dict(raw=0.0, y=0.0, dW=0.0, dgamma=0.0, dbeta=0.0, pool=0.0, head=0.0, dx=0.0, stats=0.0)
+
+    def add_expected(view, g):
+        assert view.is_full
+        bid = view.buf.id
+        expected[bid] = g if bid not in expected else expected[bid] + g
+
+    def upd(k, e, name):
+        if verbose:
+            print('%-8s %-34s %.3e' % (k, name, e))
+        worst[k] = max(worst[k], e)
+
+    for k, n in enumerate(net.nodes):
+        if n.kind == 'conv':
+            x = act(n.x)
+            if n.x.buf.is_input:
+                x = x[:, :3]
+            w = P[n.conv_key + '.weight']
+            gamma, beta = P[n.bn_key + '.weight'], P[n.bn_key + '.bias']
+            stride, pad = (n.sh, n.sw), (n.ph, n.pw)
+            raw_h = _nchw(eng.act[n.raw.id], n.raw.full(), N)
+            upd('raw', rel(raw_h, O.conv_raw(x, w, stride, pad)), n.name)
+            res = act(n.residual) if n.residual is not None else None
+            y_ref, mean, var = O.bn_act_fwd(raw_h, gamma, beta, n.eps, n.relu, res)
+            upd('y', rel(act(n.y), y_ref), n.name)
+            st = eng.stats[n.st_off:n.st_off + 2 * n.K].cpu()
+            upd('stats', max(rel(st[:n.K], mean), rel(st[n.K:], 1.0 / torch.sqrt(var + n.eps))), n.name)
+            gy = grd(n.y)
+            d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy)
+            upd('dgamma', rel(G[n.bn_key + '.weight'], dg), n.name)
+            upd('dbeta', rel(G[n.bn_key + '.bias'], db), n.name)
+            need_dx = not n.x.buf.is_input
+            dw, dx = O.conv_bwd(x, w, d_raw, stride, pad, need_dx)
+            upd('dW', rel(G[n.conv_key + '.weight'], dw), n.name)
+            if need_dx:
+                add_expected(n.x, dx)
+            if dres is not None:
+                add_expected(n.residual, dres)
+        elif n.kind in ('max', 'avg'):
+            x = act(n.x)
+            upd('pool', rel(act(n.y), O.pool_fwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw))), n.name)
+            add_expected(n.x, O.pool_bwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw), grd(n.y)))
+        elif n.kind == 'head':
+            x = act(n.x)
+            W, b = P[n.key + '.weight'], P[n.key + '.bias']
+            m = mask[:N] if (n.dropout and mask is not None) else None
+            feat, logits = O.head_fwd(x, W, b, m)
+            upd('head', rel(n.logits[:N].cpu(), logits), n.name + ':logits')
+            dl = n.dlogits[:N].cpu()
+            dx, dW, db = O.head_bwd(x, W, b, m, dl)
+            upd('head', rel(G[n.key + '.weight'], dW), n.name + ':dW')
+            upd('head', rel(G[n.key + '.bias'], db), n.name + ':db')
+            add_expected(n.x, dx)
+    for bid, g in expected.items():
+        b = net.bufs[bid]
+        upd('dx', rel(_nchw(eng.grad[bid], b.full(), N), g), b.name)
+    return worst

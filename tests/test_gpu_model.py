@@ -1,0 +1,151 @@
+"""Parity of the HIP backbone with the CPU oracle on identical weights, inputs and dropout mask.
+
+Train mode: random-init BatchNorm networks are chaotic (the fp32 oracle itself moves its logits by 1.6e-4
+for a 1e-6 input perturbation, and by 0.14 rel under bf16 storage), so every node of the plan is checked
+locally against oracle/ops.py on the HIP path's own inputs -- forward, backward, all parameter gradients --
+and the end-to-end distance is bounded by the oracle's own bf16-vs-fp32 distance.  Eval mode (fixed
+statistics) is not chaotic and is compared end to end."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from local_parity import check_plan, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name, nc, B, storage='bf16', seed=0):
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    from oracle import tv_models
+    torch.manual_seed(seed)
+    hip = get_namebrand_model(name, nc, max_batch=B)
+    sd = {k: v.detach().cpu().clone() for k, v in hip.state_dict().items()}
+    ora = tv_models.get_namebrand_model(name, nc, storage=storage)
+    ora.load_state_dict(sd, strict=True)
+    return hip, ora
+
+
+def _loss(out, y):
+    if isinstance(out, tuple):
+        return F.cross_entropy(out[0], y) + 0.4 * F.cross_entropy(out[1], y)
+    return F.cross_entropy(out, y)
+
+
+@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224)])
+def test_train_step_local_parity(name, nc, B, S):
+    hip, ora = _pair(name, nc, B)
+    x = torch.rand(B, 3, S, S)
+    y = torch.randint(0, nc, (B,))
+    mask = None
+    if name == 'inception_v3':
+        mask = torch.rand(B, 2048) > 0.5
+        hip.set_dropout_mask(mask.cuda())
+        ora.dropout_mask = mask
+    hip.train()
+    out_h = hip(x.cuda())
+    loss_h = _loss(out_h, y.cuda())
+    loss_h.backward()
+    worst = check_plan(hip, B, mask)
+    print(name, 'node-local worst rel errors:', {k: '%.2e' % v for k, v in worst.items()})
+    assert worst['raw'] < 3e-3 and worst['y'] < 3e-3 and worst['pool'] < 3e-3
+    assert worst['stats'] < 1e-4
+    assert worst['head'] < 1e-4
+    assert worst['dW'] < 1e-2 and worst['dgamma'] < 1e-2 and worst['dbeta'] < 1e-2
+    assert worst['dx'] < 1.5e-2
+    # global: same loss within the oracle's own bf16-vs-fp32 sensitivity
+    ora.train()
+    loss_o = _loss(ora(x), y)
+    print('loss hip %.5f oracle(bf16 storage) %.5f' % (loss_h.item(), loss_o.item()))
+    assert abs(loss_h.item() - loss_o.item()) < 0.1 * abs(loss_o.item())
+    # BN bookkeeping
+    for k, b in hip.named_buffers():
+        if k.endswith('num_batches_tracked'):
+            assert int(b.item()) == 1
+
+
+@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224)])
+def test_eval_forward_end_to_end(name, nc, B, S):
+    hip, ora = _pair(name, nc, B)
+    x = torch.rand(B, 3, S, S)
+    # calibrate running statistics to this batch (momentum 1) so eval activations stay O(1)
+    for m in ora.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    ora.train()
+    with torch.no_grad():
+        ora(x)
+    hip.load_state_dict(ora.state_dict())
+    hip.eval(); ora.eval()
+    with torch.no_grad():
+        eo = ora(x)
+        eh = hip(x.cuda()).cpu()
+    ob = {k: v for k, v in ora.state_dict().items()}
+    from oracle import tv_models
+    o32 = tv_models.get_namebrand_model(name, nc, storage='fp32')
+    o32.load_state_dict(ob)
+    o32.eval()
+    with torch.no_grad():
+        e32 = o32(x)
+    r, r32 = rel(eh, eo), rel(eh, e32)
+    print(name, 'eval logits rel vs bf16-storage oracle %.3e, vs fp32 oracle %.3e (oracle bf16 vs fp32 %.3e)'
+          % (r, r32, rel(eo, e32)))
+    # random-init logits are ill-conditioned under ANY bf16 storage (oracle bf16 vs fp32: 0.28 inception,
+    # 0.04 resnet18); the HIP path must sit well inside that envelope and next to the bf16-storage oracle
+    assert r < 0.35 * rel(eo, e32) + 2e-3
+    assert r32 < 1.25 * rel(eo, e32) + 2e-3
+
+
+def test_fused_step_equals_autograd_surface_and_adam_oracle():
+    """fit_batch (one fused HIP program) == reference-style training_step + torch Adam on the same model."""
+    from ifcb_classifier_amd.neuston_models import NeustonModel
+    from oracle import ops as O
+    import argparse
+    B, nc = 4, 5
+    hp = argparse.Namespace(MODEL='resnet18', classes=list('abcde'), pretrained=False, batch_size=B)
+    torch.manual_seed(3)
+    m = NeustonModel(hp)
+    x = torch.rand(B, 3, 224, 224).cuda()
+    y = torch.randint(0, nc, (B,)).cuda()
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # reference-style: forward, loss, backward -> grads
+    m.train()
+    out = m.training_step((x, y, ['a'] * B), 0)
+    out['loss'].backward()
+    eng = m.model.engine
+    g_ref = eng.G.clone()
+    p0 = eng.P.clone()
+    loss_ref = out['loss'].item()
+    # restore, then fused step
+    m.load_state_dict(sd0)
+    eng.nbt.zero_(); eng.M.zero_(); eng.V.zero_(); eng.step_count = 0
+    m.fit_batch(x, y)
+    torch.cuda.synchronize()
+    assert abs(eng.loss.item() - loss_ref) < 1e-5 * max(1, abs(loss_ref))
+    # same forward bits; dlogits come from torch's CE backward on one side and the fused kernel on the other
+    assert rel(eng.G, g_ref) < 1e-2
+    g_ref = eng.G.clone()
+    pn, mn, vn = O.adam_step(p0.cpu(), g_ref.cpu(), torch.zeros_like(p0).cpu(), torch.zeros_like(p0).cpu(), 1)
+    assert rel(eng.P.cpu(), pn) < 1e-6
+    assert (eng.P.cpu() - pn).abs().max().item() < 1e-6
+    assert rel(eng.M.cpu(), mn) < 1e-6 and rel(eng.V.cpu(), vn) < 1e-5
+    assert abs(m.epoch_train_loss() - loss_ref) < 1e-5 * max(1, abs(loss_ref))
+
+
+def test_state_dict_keys_match_oracle():
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    from oracle import tv_models
+    for name, nc in (('inception_v3', 100), ('resnet18', 2), ('resnet50', 5)):
+        hip = get_namebrand_model(name, nc, max_batch=1)
+        ora = tv_models.get_namebrand_model(name, nc)
+        sh, so = hip.state_dict(), ora.state_dict()
+        assert list(sh.keys()) == list(so.keys())
+        for k in sh:
+            assert tuple(sh[k].shape) == tuple(so[k].shape), k
+        assert [k for k, _ in hip.named_parameters()] == [k for k, _ in ora.named_parameters()]
+        del hip
+
+
+def test_unknown_model_raises_keyerror():
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    with pytest.raises(KeyError, match='model unknown'):
+        get_namebrand_model('efficientnet_b4', 10)
