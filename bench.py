@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""Headline benchmark: inception_v3 100-class bf16 TRAIN on synthetic IFCB ROIs (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one per-GPU batch of 256 synthetic ROIs that are already
+resident in HBM as ragged u8 images: on-GPU PIL-exact resize/normalise -> forward -> CE(+0.4 aux) ->
+backward -> (gradient all-reduce over RCCL when N>1, overlapped with backward) -> Adam -> bf16 weight
+repack.  Rank 0 prints ONE JSON line.  ``roofline`` is measured with HIP events recorded around every
+launch of the timed steps themselves (ifcbk_run_program_ev, no extra synchronisation); ``cpu_baseline``
+times the CPU oracle (the reference's torch-CPU arithmetic) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBPS = 8000.0
+TRAIN_GFLOP_PER_IMG = 34.26          # fwd + dgrad + wgrad, conv1a has no dgrad
+
+
+def synth_rois(n, seed, device):
+    """u8 grayscale ROIs, h,w ~ U{32..299}, concatenated; returns device tensors."""
+    g = torch.Generator().manual_seed(seed)
+    hs = torch.randint(32, 300, (n,), generator=g, dtype=torch.int32)
+    ws = torch.randint(32, 300, (n,), generator=g, dtype=torch.int32)
+    sizes = hs.long() * ws.long()
+    offs = torch.zeros(n, dtype=torch.int64)
+    offs[1:] = torch.cumsum(sizes, 0)[:-1]
+    total = int(sizes.sum())
+    pix = torch.randint(0, 256, (total,), generator=g, dtype=torch.uint8)
+    return dict(pixels=pix.to(device), offs=offs.to(device), hs=hs.to(device), ws=ws.to(device),
+                max_h=int(hs.max()), max_w=int(ws.max()), in_channels=1), (hs, ws, offs, pix)
+
+
+def cpu_baseline(batch, steps, warm, seed=1234):
+    """the reference's CPU path restated by the oracle: PIL L->RGB->resize->ToTensor per ROI, then the
+    fp32 torch-CPU train step (loss = CE + 0.4 CE_aux, Adam 1e-3; neuston_models.py:63-86)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import tv_models
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    model = tv_models.get_namebrand_model('inception_v3', 100, storage='fp32')
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    _, (hs, ws, offs, pix) = synth_rois(batch, seed, 'cpu')
+    y = torch.randint(0, 100, (batch,), generator=torch.Generator().manual_seed(seed))
+
+    def step():
+        imgs = []
+        for i in range(batch):
+            a = pix[offs[i]:offs[i] + int(hs[i]) * int(ws[i])].view(int(hs[i]), int(ws[i])).numpy()
+            im = Image.fromarray(a, 'L').convert('RGB').resize((299, 299), Image.BILINEAR)
+            imgs.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float().div(255))
+        x = torch.stack(imgs)
+        out = model(x)
+        loss = crit(out.logits, y) + 0.4 * crit(out.aux_logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    for _ in range(warm):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 3), unit='images/s', cores=cores, kind='port',
+                sample='%d train steps of batch %d (PIL resize + fp32 torch-CPU oracle fwd/bwd/Adam), %.1f s'
+                       % (steps, batch, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE config: 256)')
+    ap.add_argument('--classes', type=int, default=100)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-events', action='store_true', help='do not record per-launch HIP events in the timed region')
+    ap.add_argument('--dump-ops', default=None, help='write the per-op timing table (JSON) here')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from ifcb_classifier_amd import graph, _lib
+    from ifcb_classifier_amd.engine import Engine
+    B = args.batch
+    net = graph.build('inception_v3', args.classes, pretrained=False)
+    eng = Engine(net, device=local, max_batch=B)
+    eng.init_weights(seed=1234)
+    if world > 1:
+        dist.broadcast(eng.P, 0)
+        eng.params_changed()
+    rois, _ = synth_rois(B, 1234 + rank, eng.dev)
+    eng.target[:B].copy_(torch.randint(0, args.classes, (B,), generator=torch.Generator().manual_seed(99 + rank)))
+    pl = eng.plan(B)
+    use_ev = (not args.no_events) and world == 1 and args.steps <= 256
+
+    def allred(t):
+        return dist.all_reduce(t, async_op=True)
+
+    def step(k=None):
+        eng.load_rois(**rois)
+        if world > 1:
+            eng.train_step_ddp(B, world, allred)
+        else:
+            eng.train_step(B, ev_slot=k)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k if use_ev else None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=eng.dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(eng.loss.item())
+
+    out = None
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        out = {
+            'metric': 'train images/sec, inception_v3 299^2 IFCB ROIs', 'value': round(ips, 1), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'inception_v3 100-class bf16 TRAIN, batch %d per GPU, synthetic u8 ROIs h,w~U{32..299} '
+                                   'resized on-GPU to 299x299 (BASELINE.json configs[1])' % B,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'optimizer': 'adam lr=1e-3',
+                       'loss': 'CE + 0.4*CE_aux'},
+            'train_tflops': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3, 2),
+            'mfma_frac_whole_step': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
+            'final_loss': round(loss, 4),
+        }
+        if use_ev:
+            n = pl.step.n
+            ms = (C.c_float * n)()
+            agg = {}
+            for k in range(args.steps):
+                eng.ctx.call('ifcbk_program_times', k, n, ms)
+                for j in range(n):
+                    op = pl.step.arr[j]
+                    nm = C.create_string_buffer(64)
+                    eng.ctx.lib.ifcbk_op_kernel(C.byref(op), nm, 64)
+                    fl, by = C.c_double(), C.c_double()
+                    eng.ctx.lib.ifcbk_op_cost(C.byref(op), C.byref(fl), C.byref(by))
+                    key = nm.value.decode() or _lib.OP_NAMES[op.kind]
+                    a = agg.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                    a['ms'] += ms[j]
+                    a['flops'] += fl.value
+                    a['bytes'] += by.value
+                    a['launches'] += 1
+            conv = {k: v for k, v in agg.items() if k.startswith('conv_')}
+            dom = max(conv, key=lambda k: conv[k]['ms'])
+            d = conv[dom]
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                               'avg_launch_ms': round(d['ms'] / d['launches'], 5), 'launches': d['launches'],
+                               'flops_per_launch': d['flops'] / d['launches']}
+            call = sum(v['flops'] for v in conv.values()) / (sum(v['ms'] for v in conv.values()) * 1e-3) / 1e12
+            out['conv_all'] = {'achieved_tflops': round(call, 2), 'frac': round(call / MFMA_BF16_PEAK_TFLOPS, 4),
+                               'ms_per_step': round(sum(v['ms'] for v in conv.values()) / args.steps, 3)}
+            out['ms_per_step_by_kernel'] = {k: round(v['ms'] / args.steps, 3) for k, v in
+                                            sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+            if args.dump_ops:
+                rows = []
+                eng.ctx.call('ifcbk_program_times', args.steps - 1, n, ms)
+                for j in range(n):
+                    op = pl.step.arr[j]
+                    nm = C.create_string_buffer(64)
+                    eng.ctx.lib.ifcbk_op_kernel(C.byref(op), nm, 64)
+                    fl, by = C.c_double(), C.c_double()
+                    eng.ctx.lib.ifcbk_op_cost(C.byref(op), C.byref(fl), C.byref(by))
+                    rows.append(dict(i=j, tag=pl.step.tags[j], op=_lib.OP_NAMES[op.kind], kernel=nm.value.decode(),
+                                     ms=ms[j], gflop=fl.value / 1e9, mbytes=by.value / 1e6))
+                with open(args.dump_ops, 'w') as f:
+                    json.dump(rows, f)
+        if world == 1 and not args.no_cpu_baseline:
+            del eng
+            torch.cuda.empty_cache()
+            out['cpu_baseline'] = cpu_baseline(batch=32, steps=3, warm=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

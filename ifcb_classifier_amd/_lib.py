@@ -91,6 +91,9 @@ _PROTOS = {
     'ifcbk_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _vp]),
     'ifcbk_nhwc_to_nchw_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ifcbk_run_program': (_i, [_vp, C.POINTER(Op), _i, _vp, C.POINTER(_f)]),
+    'ifcbk_run_program_ev': (_i, [_vp, C.POINTER(Op), _i, _vp, _i]),
+    'ifcbk_program_times': (_i, [_vp, _i, _i, C.POINTER(_f)]),
+    'ifcbk_op_kernel': (_i, [C.POINTER(Op), C.c_char_p, _sz]),
     'ifcbk_op_cost': (_i, [C.POINTER(Op), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -10,8 +10,11 @@ struct ifcbk_ctx {
     int device;
     void* ws;            // workspace arena (split-K slabs, resize tables)
     size_t ws_bytes;
+    void* zeros;         // 4 KiB of zeros: source address of padded / out-of-range LDS-DMA chunks
     hipEvent_t* ev;      // profiling events for ifcbk_run_program
     int n_ev;
+    hipEvent_t* slot_ev[256];   // ifcbk_run_program_ev
+    int slot_n[256];
     char err[512];
 };
 
@@ -77,4 +80,6 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const fastdiv_t& f) {
     return (__umulhi(n, f.mul) + n) >> f.shift;
 }
 
+int ifcbk_conv_fwd_nt(int K);
+int ifcbk_conv_wgrad_mt(int K);
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -6,7 +6,9 @@
 // input pixel.  One kernel serves forward and dgrad: dgrad is the same gather over dy with the flipped,
 // transposed filter and "input dilation" (positions not divisible by the stride contribute zero).
 //
-// Tile: 128 pixels x (32*NT) channels x 32 k per step, 4 waves (2x2), v_mfma_f32_16x16x32_bf16.
+// Tile: 128 pixels x (32*NT) channels x 64 k per step, 4 waves (2x2), v_mfma_f32_16x16x32_bf16; both operand
+// tiles are staged by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a 2-stage ring: the DMA of
+// tile k+1 is in flight while tile k is multiplied.
 // The filter fragment is the MFMA A operand and the pixel fragment the B operand, so each lane ends with
 // 4 consecutive CHANNELS of one pixel (one 8-byte LDS store per tile); the block tile is then written out
 // through LDS as whole 16-byte chunks (coalesced rows) and the BatchNorm batch statistics (sum, sum of
@@ -20,6 +22,7 @@ struct ConvArgs {
     const bf16_t* w;
     bf16_t* y;
     float* part;       // [mblocks][2][K] or null
+    const bf16_t* zero;   // >= 16 bytes of zeros (source of padded / out-of-range chunks)
     int H, W, C, ldx;
     int K, R, S;
     int P, Q, ldy;
@@ -31,109 +34,105 @@ struct ConvArgs {
 };
 
 constexpr int BM = 128;
-constexpr int BK = 32;
+constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS image of a tile: [rows][8 chunks of 16 B]; chunk c of row r lives at physical chunk c ^ (r & 7), which
+// makes every ds_read_b128 fragment read conflict-free.  The image is filled by LDS-DMA
+// (global_load_lds_dwordx4: destination = wave-uniform base + lane*16), so the swizzle is applied on the
+// SOURCE side: the lane that lands on (row, phys) fetches logical chunk phys ^ (row & 7).
+__device__ __forceinline__ const bf16x8_t* frag_ptr(const bf16_t* tile, int row, int chunk) {
+    return reinterpret_cast<const bf16x8_t*>(tile + row * BK + ((chunk ^ (row & 7)) << 3));
+}
 
 template <int NT>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
     constexpr int BN = 32 * NT;
-    constexpr int PB = (BN + 63) / 64;                 // B-tile load passes
     constexpr int CPR = BN / 8;                        // 16-byte chunks per output row
     constexpr int CPRP = CPR <= 4 ? 4 : CPR <= 8 ? 8 : CPR <= 16 ? 16 : 32;
     constexpr int LDC = BN + 8;                        // C-tile row stride (elements)
-    constexpr int STAGE_BYTES = 2 * (BM + BN) * BK * 2;
+    constexpr int STAGE = (BM + BN) * BK;              // elements per pipeline stage
+    constexpr int STAGE_BYTES = 2 * STAGE * 2;
     constexpr int CT_BYTES = BM * LDC * 2;
     constexpr int MAIN_BYTES = STAGE_BYTES > CT_BYTES ? STAGE_BYTES : CT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 4 * BN * 2 * 4];
-    bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                 // [2][BM*BK]
-    bf16_t* sB = sA + 2 * BM * BK;                                // [2][BN*BK]
+    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem);             // [2][A: BM*BK | B: BN*BK]
     bf16_t* sC = reinterpret_cast<bf16_t*>(smem);                 // [BM][LDC] (epilogue)
     float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);    // [4][2][BN]
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int bid = blockIdx.x;
     const int mtile = bid / a.tilesN, ntile = bid - mtile * a.tilesN;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
-    // ---- per-thread gather state: chunk column (t&3), rows (t>>2) and (t>>2)+64
-    const int lchunk = t & 3;
-    const int lrow = t >> 2;
-    const bf16_t* xrow[2];
-    int bh[2], bw[2];
-    bool rvalid[2];
+    // ---- LDS-DMA roles: one wave-instruction fills 8 tile rows (1 KiB); lane -> (row l>>3, phys chunk l&7)
+    const int lrow8 = lane >> 3;
+    const int csrc = (lane & 7) ^ lrow8;               // logical 16-byte chunk this lane fetches, every row group
+    const bf16_t* xrow[4];
+    int bh[4], bw[4];
+    bool rvalid[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = m0 + lrow + 64 * i;
-        rvalid[i] = m < a.M;
-        int mm = rvalid[i] ? m : 0;
+    for (int j = 0; j < 4; ++j) {
+        int m = m0 + (wave * 4 + j) * 8 + lrow8;
+        rvalid[j] = m < a.M;
+        int mm = rvalid[j] ? m : 0;
         int n = mm / a.PQ;
         int rem = mm - n * a.PQ;
         int p = rem / a.Q;
         int q = rem - p * a.Q;
-        bh[i] = p * a.ostr_h + a.base_h;
-        bw[i] = q * a.ostr_w + a.base_w;
-        xrow[i] = a.x + (size_t)n * a.H * a.W * a.ldx;
+        bh[j] = p * a.ostr_h + a.base_h;
+        bw[j] = q * a.ostr_w + a.base_w;
+        xrow[j] = a.x + (size_t)n * a.H * a.W * a.ldx;
     }
-    // k decode for this thread's chunk
     int kc, kr, ks;
     {
-        int k = lchunk * 8;
+        int k = csrc * 8;
         int rs = k / a.C;
         kc = k - rs * a.C;
         kr = rs / a.S;
         ks = rs - kr * a.S;
     }
-    const bf16_t* wrow[PB];
-    bool nvalid[PB];
+    const bf16_t* wrow[NT];
+    bool nvalid[NT];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        int n = lrow + 64 * i;
-        nvalid[i] = (n < BN) && (n0 + n < a.K);
-        wrow[i] = a.w + (size_t)(nvalid[i] ? n0 + n : 0) * a.Kg + lchunk * 8;
+    for (int j = 0; j < NT; ++j) {
+        int n = n0 + (j * 4 + wave) * 8 + lrow8;
+        nvalid[j] = n < a.K;
+        wrow[j] = a.w + (size_t)(nvalid[j] ? n : 0) * a.Kg + csrc * 8;
     }
-
     const int nk = (a.Kg + BK - 1) / BK;
-    uint4 ra[2], rb[PB];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int hmask = (1 << a.ish) - 1, wmask = (1 << a.isw) - 1;
 
-    auto load_tiles = [&](int kt) {
-        const bool kvalid = kr < a.R;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int hr = bh[i] + kr, wr = bw[i] + ks;
-            bool v = rvalid[i] && kvalid && hr >= 0 && wr >= 0 && ((hr & ((1 << a.ish) - 1)) == 0) &&
-                     ((wr & ((1 << a.isw) - 1)) == 0);
-            int hi = hr >> a.ish, wi = wr >> a.isw;
-            v = v && hi < a.H && wi < a.W;
-            ra[i] = v ? *reinterpret_cast<const uint4*>(xrow[i] + ((size_t)hi * a.W + wi) * a.ldx + kc) : zero4;
-        }
-        const bool kv2 = (kt * BK + lchunk * 8) < a.Kg;
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            rb[i] = (nvalid[i] && kv2) ? *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * BK) : zero4;
-        // advance (r,s,c) by BK
-        kc += BK;
-        while (kc >= a.C) {
-            kc -= a.C;
-            if (++ks == a.S) { ks = 0; ++kr; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int row = lrow + 64 * i;
-            *reinterpret_cast<uint4*>(sA + buf * BM * BK + row * BK + swz(row, lchunk) * 8) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            int row = lrow + 64 * i;
-            if (row < BN) *reinterpret_cast<uint4*>(sB + buf * BN * BK + row * BK + swz(row, lchunk) * 8) = rb[i];
-        }
-    };
+#define ISSUE_TILE(kt, stage)                                                                              \
+    {                                                                                                      \
+        bf16_t* dstA = sStage + (stage) * STAGE;                                                           \
+        bf16_t* dstB = dstA + BM * BK;                                                                     \
+        const bool kvalid = kr < a.R;                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+            int hr = bh[j] + kr, wr = bw[j] + ks;                                                          \
+            bool v = rvalid[j] && kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0); \
+            int hi = hr >> a.ish, wi = wr >> a.isw;                                                        \
+            v = v && hi < a.H && wi < a.W;                                                                 \
+            const bf16_t* src = v ? xrow[j] + ((size_t)hi * a.W + wi) * a.ldx + kc : a.zero;              \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, 0, 0); \
+        }                                                                                                  \
+        const bool kv2 = ((kt) * BK + csrc * 8) < a.Kg;                                                    \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
+            const bf16_t* src = (nvalid[j] && kv2) ? wrow[j] + (size_t)(kt) * BK : a.zero;                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstB + (j * 4 + wave) * 8 * BK), 16, 0, 0); \
+        }                                                                                                  \
+        kc += BK;                                                                                          \
+        while (kc >= a.C) {                                                                                \
+            kc -= a.C;                                                                                     \
+            if (++ks == a.S) { ks = 0; ++kr; }                                                             \
+        }                                                                                                  \
+    }
 
     f32x4_t acc[NT][4];
 #pragma unroll
@@ -141,33 +140,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    ISSUE_TILE(0, 0)
+    __syncthreads();            // hipcc drains vmcnt(0) before the barrier: tile 0 has landed for every wave
 
     const int frow = lane & 15, fchunk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        bf16x8_t fa[4], fb[NT];
+        const int stage = kt & 1;
+        if (kt + 1 < nk) ISSUE_TILE(kt + 1, stage ^ 1)
+        const bf16_t* tA = sStage + stage * STAGE;
+        const bf16_t* tB = tA + BM * BK;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            int row = wm * 64 + mt * 16 + frow;
-            fa[mt] = *reinterpret_cast<const bf16x8_t*>(sA + buf * BM * BK + row * BK + swz(row, fchunk) * 8);
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *frag_ptr(tA, wm * 64 + mt * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = *frag_ptr(tB, wn * (NT * 16) + nt * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            int row = wn * (NT * 16) + nt * 16 + frow;
-            fb[nt] = *reinterpret_cast<const bf16x8_t*>(sB + buf * BN * BK + row * BK + swz(row, fchunk) * 8);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
+        __syncthreads();        // next tile landed (vmcnt(0) drained) and this stage is free to refill
     }
+#undef ISSUE_TILE
 
     // ---- epilogue: acc -> bf16 C tile in LDS (lane: 4 consecutive channels of one pixel)
     {
@@ -296,13 +293,15 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int ifcbk_conv_fwd_nt(int K) { return pick_nt(K); }
+
 extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) { return cdiv((int64_t)d->N * d->P * d->Q, BM); }
 
 extern "C" int ifcbk_conv2d_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y,
                                 float* bn_part, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
     ConvArgs a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part; a.zero = (const bf16_t*)ctx->zeros;
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S;
     a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
@@ -317,7 +316,7 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     if (int e = check_desc(ctx, d)) return e;
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
-    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr;
+    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr; a.zero = (const bf16_t*)ctx->zeros;
     a.H = d->P; a.W = d->Q; a.C = d->K; a.ldx = d->ldy;
     a.K = d->C; a.R = d->R; a.S = d->S;
     a.P = d->H; a.Q = d->W; a.ldy = d->ldx;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
 
     uint4 ra[NA], rb[2];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_tiles = [&](int pix0) {
+    auto load_tiles = [&](int pix0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             int pix = pix0 + arow[i];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
             rb[i] = v ? *reinterpret_cast<const uint4*>(a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.ldx + bc) : zero4;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             if (t + NTHREADS * i < BKP * CA)
@@ -223,6 +223,8 @@ void launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
 }
 
 }  // namespace
+
+int ifcbk_conv_wgrad_mt(int K) { return pick_mt(K); }
 
 extern "C" size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc* d) { return make_plan(d).ws; }
 

@@ -13,6 +13,11 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     ifcbk_ctx* c = (ifcbk_ctx*)calloc(1, sizeof(ifcbk_ctx));
     if (!c) return IFCBK_ENOMEM;
     c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&c->zeros, 4096) != hipSuccess ||
+        hipMemset(c->zeros, 0, 4096) != hipSuccess) {
+        free(c);
+        return IFCBK_EHIP;
+    }
     *out = c;
     return IFCBK_OK;
 }
@@ -20,8 +25,13 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
 extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     if (!c) return IFCBK_OK;
     if (c->ws) (void)hipFree(c->ws);
+    if (c->zeros) (void)hipFree(c->zeros);
     for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     free(c->ev);
+    for (int s = 0; s < 256; ++s) {
+        for (int i = 0; i < c->slot_n[s]; ++i) (void)hipEventDestroy(c->slot_ev[s][i]);
+        free(c->slot_ev[s]);
+    }
     free(c);
     return IFCBK_OK;
 }
@@ -116,6 +126,53 @@ extern "C" int ifcbk_run_program(ifcbk_ctx* c, const ifcbk_op* ops, int n, void*
     if (op_ms) {
         IFCBK_HIP(c, hipStreamSynchronize(st));
         for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->ev[i], c->ev[i + 1]));
+    }
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_run_program_ev(ifcbk_ctx* c, const ifcbk_op* ops, int n, void* stream, int slot) {
+    if (!c || slot < 0 || slot >= 256 || (!ops && n > 0)) return IFCBK_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->slot_n[slot] < n + 1) {
+        hipEvent_t* ev = (hipEvent_t*)realloc(c->slot_ev[slot], sizeof(hipEvent_t) * (n + 1));
+        if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "run_program_ev: event pool");
+        c->slot_ev[slot] = ev;
+        for (int i = c->slot_n[slot]; i < n + 1; ++i) IFCBK_HIP(c, hipEventCreate(&ev[i]));
+        c->slot_n[slot] = n + 1;
+    }
+    hipEvent_t* ev = c->slot_ev[slot];
+    IFCBK_HIP(c, hipEventRecord(ev[0], st));
+    for (int i = 0; i < n; ++i) {
+        int e = run_one(c, &ops[i], stream);
+        if (e) return e;
+        IFCBK_HIP(c, hipEventRecord(ev[i + 1], st));
+    }
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_program_times(ifcbk_ctx* c, int slot, int n, float* op_ms) {
+    if (!c || slot < 0 || slot >= 256 || !op_ms || c->slot_n[slot] < n + 1) return IFCBK_EINVAL;
+    for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->slot_ev[slot][i], c->slot_ev[slot][i + 1]));
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
+    if (!o || !name || cap < 1) return IFCBK_EINVAL;
+    name[0] = 0;
+    switch (o->kind) {
+        case IFCBK_OP_CONV_FWD: snprintf(name, cap, "conv_igemm_bf16<%d>", ifcbk_conv_fwd_nt(o->u.conv.K)); break;
+        case IFCBK_OP_CONV_DGRAD: snprintf(name, cap, "conv_igemm_bf16<%d>", ifcbk_conv_fwd_nt(o->u.conv.C)); break;
+        case IFCBK_OP_CONV_WGRAD: snprintf(name, cap, "conv_wgrad_bf16<%d>", ifcbk_conv_wgrad_mt(o->u.conv.K)); break;
+        case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
+        case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
+        case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;
+        case IFCBK_OP_MAXPOOL_FWD: snprintf(name, cap, "maxpool_fwd_kernel"); break;
+        case IFCBK_OP_MAXPOOL_BWD: snprintf(name, cap, "maxpool_bwd_kernel"); break;
+        case IFCBK_OP_AVGPOOL_FWD: snprintf(name, cap, "avgpool_fwd_kernel"); break;
+        case IFCBK_OP_AVGPOOL_BWD: snprintf(name, cap, "avgpool_bwd_kernel"); break;
+        case IFCBK_OP_ADAM: snprintf(name, cap, "adam_kernel"); break;
+        case IFCBK_OP_WEIGHT_PACK: snprintf(name, cap, "weight_pack_kernel"); break;
+        default: break;
     }
     return IFCBK_OK;
 }

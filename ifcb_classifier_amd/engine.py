@@ -398,6 +398,79 @@ class Engine:
             allops.extend(prog_ops)
         pl.step = Program(allops)
         pl.step_adam_idx = pl.step.find(_lib.OP_ADAM)[0]
+        # data-parallel variant: fwd+loss | backward segments (all-reduce launched after each) | adam+pack
+        fl = OpList()
+        fl.extend(fwd_t)
+        fl.extend(lossl)
+        pl.fwd_loss = Program(fl)
+        ap = OpList()
+        ap.extend(opt)
+        ap.extend(pack)
+        pl.adam_pack = Program(ap)
+        pl.bwd_list = bwd
+        pl.ddp_segs = None
+        return pl
+
+    def _op_param_offsets(self, o):
+        """element offsets (into the flat gradient buffer) of the parameter tensors a backward op writes."""
+        base = self.G.data_ptr()
+        if o.kind == _lib.OP_CONV_WGRAD:
+            return [(o.p[2] - base) // 4]
+        if o.kind == _lib.OP_BN_BWD:
+            return [(o.p[8] - base) // 4, (o.p[9] - base) // 4]
+        if o.kind == _lib.OP_HEAD_BWD:
+            return [(o.p[4] - base) // 4, (o.p[5] - base) // 4]
+        return []
+
+    def ddp_segments(self, pl, nseg=8):
+        """split the backward list into <= nseg runs whose finished gradients form a contiguous tail
+        [lo, prev_lo) of the flat buffer, so each run's all-reduce can start while later runs compute."""
+        if pl.ddp_segs is not None:
+            return pl.ddp_segs
+        padded = {o: (n + 3) // 4 * 4 for (o, n, _s, _k, _n) in self.poff.values()}
+        ops = pl.bwd_list.ops
+        total = self.nparam_padded
+        target = total / float(nseg)
+        segs, start, prev_lo, lo_min, produced = [], 0, total, total, 0
+        for k, o in enumerate(ops):
+            for off in self._op_param_offsets(o):
+                lo_min = min(lo_min, off)
+                produced += padded[off]
+            last = k == len(ops) - 1
+            closed = produced == total - lo_min          # every tensor at or above lo_min is finished
+            if last:
+                assert closed and lo_min == 0, 'backward list does not cover the flat gradient buffer'
+            if (closed and prev_lo - lo_min >= target) or last:
+                sub = OpList()
+                sub.ops, sub.tags = ops[start:k + 1], pl.bwd_list.tags[start:k + 1]
+                segs.append((Program(sub), lo_min, prev_lo))
+                start, prev_lo = k + 1, lo_min
+        pl.ddp_segs = segs
+        return segs
+
+    def train_step_ddp(self, N, world, all_reduce):
+        """data-parallel step: gradient all-reduce (sum) of each finished tail bucket is launched right after
+        the backward segment that completes it and overlaps the remaining backward; Adam divides by world."""
+        pl = self.plan(N)
+        self.ensure_packed(pl)
+        self.make_dropout_mask(N)
+        self.run(pl.fwd_loss)
+        works = []
+        for prog, lo, hi in self.ddp_segments(pl):
+            self.run(prog)
+            if hi > lo:
+                works.append(all_reduce(self.G[lo:hi]))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.step_count += 1
+        a = pl.adam_pack.arr[0]
+        a.i[1] = self.step_count
+        a.f[5] = 1.0 / world
+        self.run(pl.adam_pack)
+        self.nbt += 1
+        self.loss_sum += self.loss
+        self.eval_stats_ready = False
         return pl
 
     # ------------------------------------------------------------------ execution
@@ -487,14 +560,17 @@ class Engine:
         self.packed = False
         self.eval_stats_ready = False
 
-    def train_step(self, N, op_ms=None):
+    def train_step(self, N, op_ms=None, ev_slot=None):
         """one fused launch list: fwd + CE(+0.4 aux) + bwd + Adam + weight repack; loss stays on device."""
         pl = self.plan(N)
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
         self.step_count += 1
         pl.step.arr[pl.step_adam_idx].i[1] = self.step_count
-        self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)
+        if ev_slot is not None:
+            self.ctx.call('ifcbk_run_program_ev', pl.step.arr, pl.step.n, self.stream(), int(ev_slot))
+        else:
+            self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)
         self.nbt += 1
         self.loss_sum += self.loss
         self.eval_stats_ready = False

@@ -204,6 +204,14 @@ typedef struct {
 /* op_ms (nullable, host array of n floats): when given, every op is bracketed by HIP events on
  * `stream`, the stream is synchronised at the end and per-op milliseconds are returned.             */
 int ifcbk_run_program(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, float* op_ms);
+/* Non-blocking timing: same launches, with HIP events recorded on `stream` around every op into event
+ * slot `slot` (0..255, one slot per in-flight program run); nothing is synchronised.  After the caller has
+ * synchronised the stream, ifcbk_program_times returns the n per-op milliseconds of that slot.           */
+int ifcbk_run_program_ev(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, int slot);
+int ifcbk_program_times(ifcbk_ctx*, int slot, int n, float* op_ms);
+/* name of the (dominant) device kernel an op launches, e.g. "conv_igemm_bf16<4>" (as rocprofv3 prints it
+ * inside its mangled/demangled symbol); returns 0 and "" for ops without a compute kernel               */
+int ifcbk_op_kernel(const ifcbk_op* op, char* name, size_t cap);
 /* algorithmic work of one op: flops (MAC*2 of conv/FC only) and minimum HBM bytes                   */
 int ifcbk_op_cost(const ifcbk_op* op, double* flops, double* bytes);
 
