@@ -43,13 +43,26 @@ def synth_rois(n, seed, device):
                 max_h=int(hs.max()), max_w=int(ws.max()), in_channels=1), (hs, ws, offs, pix)
 
 
-def cpu_baseline(batch, steps, warm, seed=1234):
+def host_cores():
+    """threads this process may really use (cgroup quota and affinity, not the machine's core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
     """the reference's CPU path restated by the oracle: PIL L->RGB->resize->ToTensor per ROI, then the
-    fp32 torch-CPU train step (loss = CE + 0.4 CE_aux, Adam 1e-3; neuston_models.py:63-86)."""
+    fp32 torch-CPU train step (loss = CE + 0.4 CE_aux, Adam 1e-3; neuston_models.py:63-86).  Bounded: one
+    warm-up step, then steps until ~budget_s of CPU work (at least 1, at most 5)."""
     import numpy as np
     from PIL import Image
     from oracle import tv_models
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
     model = tv_models.get_namebrand_model('inception_v3', 100, storage='fp32')
@@ -73,14 +86,18 @@ def cpu_baseline(batch, steps, warm, seed=1234):
         opt.step()
         return loss.item()
 
-    for _ in range(warm):
-        step()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    step()
+    warm = time.perf_counter() - t0
+    print('[cpu_baseline] warm-up step of batch %d on %d threads: %.1f s' % (batch, cores, warm), file=sys.stderr, flush=True)
+    steps = int(max(1, min(5, (budget_s - warm) // max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for k in range(steps):
         step()
+        print('[cpu_baseline] step %d/%d' % (k + 1, steps), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return dict(value=round(batch * steps / dt, 3), unit='images/s', cores=cores, kind='port',
-                sample='%d train steps of batch %d (PIL resize + fp32 torch-CPU oracle fwd/bwd/Adam), %.1f s'
+                sample='%d train steps of batch %d after 1 warm-up (PIL resize + fp32 torch-CPU oracle fwd/bwd/Adam), %.1f s'
                        % (steps, batch, dt))
 
 
@@ -214,7 +231,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del eng
             torch.cuda.empty_cache()
-            out['cpu_baseline'] = cpu_baseline(batch=32, steps=3, warm=1)
+            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

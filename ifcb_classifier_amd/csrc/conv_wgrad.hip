@@ -16,38 +16,46 @@ struct WgradArgs {
     const bf16_t* x;
     const bf16_t* dy;
     float* slab;      // [nsplit][K][RSC]
+    const bf16_t* zero;
     int H, W, C, ldx;
     int K, R, S;
     int P, Q, ldy;
     int sh, sw, ph, pw;
     int M;            // N*P*Q pixels
     int RSC;
-    int split_len;    // pixels per split (multiple of 32)
+    int split_len;    // pixels per split (multiple of BKP)
     int tilesN;       // column tiles
     fastdiv_t fPQ, fQ;
 };
 
 constexpr int NTHREADS = 256;
-constexpr int BKP = 32;     // pixels per step
-constexpr int BNW = 128;    // columns per block
-constexpr int LDB = BNW + 16;
+constexpr int BKP = 64;     // pixels per step
+constexpr int BNW = 128;    // (r,s,c) columns per block
+constexpr int TW = 128;     // LDS image width (elements) of BOTH tiles: [BKP rows][16 chunks of 16 B]
+constexpr int TILE = BKP * TW;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ s16x4_t tr_read(const bf16_t* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4_t*)(p));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+// Both tiles are pixel-major (the reduction index is the ROW), 256-byte rows, filled by LDS-DMA.  16-byte
+// chunk c of row r lives at physical chunk c ^ ((r & 7) << 1): the 8 rows one half-wave touches in a
+// ds_read_b64_tr_b16 then fall into 8 different 32-byte bank slots (conflict-free transposing reads).
+__device__ __forceinline__ const bf16_t* tr_addr(const bf16_t* tile, int row, int col) {
+    int c16 = col >> 3;
+    return tile + row * TW + ((c16 ^ ((row & 7) << 1)) << 3) + (col & 7);
 }
 
 template <int MT>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
     constexpr int BMW = 32 * MT;
-    constexpr int LDA = BMW + 16;
-    constexpr int CA = BMW / 8;                      // dy chunks per pixel
-    constexpr int NA = (BKP * CA + NTHREADS - 1) / NTHREADS;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BKP * LDA + 2 * BKP * LDB];
-    bf16_t* sA = smem;
-    bf16_t* sB = smem + 2 * BKP * LDA;
+    constexpr int CA = BMW / 8;                      // valid dy chunks per pixel row
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TILE];     // [stage][A | B]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = blockIdx.x;
     const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
@@ -56,62 +64,48 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
     const int pix_begin = split * a.split_len;
     const int pix_end = min(pix_begin + a.split_len, a.M);
 
-    // B (gathered x): thread -> column chunk cb, pixel rows pb and pb+16
-    const int cb = t & 15, pb = t >> 4;
-    int br, bs, bc;
-    bool colvalid;
-    {
-        int j = n0 + cb * 8;
-        colvalid = j < a.RSC;
-        int jj = colvalid ? j : 0;
-        int rs = jj / a.C;
-        bc = jj - rs * a.C;
-        br = rs / a.S;
-        bs = rs - br * a.S;
-    }
-    // A (dy): flat chunk ids
-    int arow[NA], acol[NA];
-    bool avalid[NA];
+    // LDS-DMA roles: wave-instruction j of wave w fills LDS rows (w*4+j)*4 .. +3; lane -> (row l>>4, phys chunk l&15)
+    const int lrow4 = lane >> 4, phys = lane & 15;
+    // logical chunk per instruction parity (row & 7 = (j&1)*4 + lrow4)
+    int ac16[2], bcol_r[2], bcol_s[2], bcol_c[2];
+    bool avalid[2], bvalid[2];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        int e = t + NTHREADS * i;
-        arow[i] = e / CA;
-        acol[i] = e - arow[i] * CA;
-        avalid[i] = (e < BKP * CA) && (k0 + acol[i] * 8 < a.K);
+    for (int par = 0; par < 2; ++par) {
+        int c16 = phys ^ (((par * 4 + lrow4) & 7) << 1);
+        ac16[par] = c16;
+        avalid[par] = (c16 < CA) && (k0 + c16 * 8 < a.K);
+        int jcol = n0 + c16 * 8;
+        bvalid[par] = jcol < a.RSC;
+        int jj = bvalid[par] ? jcol : 0;
+        int rs = jj / a.C;
+        bcol_c[par] = jj - rs * a.C;
+        bcol_r[par] = rs / a.S;
+        bcol_s[par] = rs - bcol_r[par] * a.S;
     }
 
-    uint4 ra[NA], rb[2];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_tiles = [&](int pix0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int pix = pix0 + arow[i];
-            bool v = avalid[i] && pix < pix_end;
-            ra[i] = v ? *reinterpret_cast<const uint4*>(a.dy + (size_t)pix * a.ldy + k0 + acol[i] * 8) : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int pix = pix0 + pb + 16 * i;
-            bool v = colvalid && pix < pix_end;
-            uint32_t pp = v ? (uint32_t)pix : 0u;
-            uint32_t n = fdiv(pp, a.fPQ);
-            uint32_t rem = pp - n * a.fPQ.d;
-            uint32_t p = fdiv(rem, a.fQ);
-            uint32_t q = rem - p * a.fQ.d;
-            int hi = (int)p * a.sh - a.ph + br, wi = (int)q * a.sw - a.pw + bs;
-            v = v && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-            rb[i] = v ? *reinterpret_cast<const uint4*>(a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.ldx + bc) : zero4;
-        }
-    };
-    auto store_tiles = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-            if (t + NTHREADS * i < BKP * CA)
-                *reinterpret_cast<uint4*>(sA + buf * BKP * LDA + arow[i] * LDA + acol[i] * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(sB + buf * BKP * LDB + (pb + 16 * i) * LDB + cb * 8) = rb[i];
-    };
+#define ISSUE_TILE(pix0, stage)                                                                                 \
+    {                                                                                                           \
+        bf16_t* dstA = smem + (stage) * 2 * TILE;                                                               \
+        bf16_t* dstB = dstA + TILE;                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const int par = j & 1;                                                                              \
+            const int row = (wave * 4 + j) * 4 + lrow4;                                                         \
+            const int pix = (pix0) + row;                                                                       \
+            const bool pv = pix < pix_end;                                                                      \
+            const bf16_t* srcA = (pv && avalid[par]) ? a.dy + (size_t)pix * a.ldy + k0 + ac16[par] * 8 : a.zero; \
+            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(dstA + (wave * 4 + j) * 4 * TW), 16, 0, 0);   \
+            bool v = pv && bvalid[par];                                                                         \
+            uint32_t pp = v ? (uint32_t)pix : 0u;                                                               \
+            uint32_t n = fdiv(pp, a.fPQ);                                                                       \
+            uint32_t rem = pp - n * a.fPQ.d;                                                                    \
+            uint32_t p = fdiv(rem, a.fQ);                                                                       \
+            uint32_t q = rem - p * a.fQ.d;                                                                      \
+            int hi = (int)p * a.sh - a.ph + bcol_r[par], wi = (int)q * a.sw - a.pw + bcol_s[par];               \
+            v = v && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;                                                \
+            const bf16_t* srcB = v ? a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.ldx + bcol_c[par] : a.zero;  \
+            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstB + (wave * 4 + j) * 4 * TW), 16, 0, 0);   \
+        }                                                                                                       \
+    }
 
     f32x4_t acc[MT][4];
 #pragma unroll
@@ -120,39 +114,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (pix_end - pix_begin + BKP - 1) / BKP;
-    if (nsteps > 0) {
-        load_tiles(pix_begin);
-        store_tiles(0);
-    }
+    if (nsteps > 0) ISSUE_TILE(pix_begin, 0)
     __syncthreads();
 
     // transposing fragment reads: lane (g, q, p) addresses LDS row 4g+q (then +16), columns col0+4p..+3
     const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
     const int trow = 4 * g + lq;
     for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) load_tiles(pix_begin + (st + 1) * BKP);
-        bf16x8_t fa[MT], fb[4];
+        const int stage = st & 1;
+        if (st + 1 < nsteps) ISSUE_TILE(pix_begin + (st + 1) * BKP, stage ^ 1)
+        const bf16_t* tA = smem + stage * 2 * TILE;
+        const bf16_t* tB = tA + TILE;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const bf16_t* base = sA + buf * BKP * LDA + trow * LDA + wm * (MT * 16) + mt * 16 + 4 * lp;
-            s16x4_t lo = tr_read(base), hi = tr_read(base + 16 * LDA);
-            fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[MT], fb[4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int col = wm * (MT * 16) + mt * 16 + 4 * lp;
+                s16x4_t lo = tr_read(tr_addr(tA, kk * 32 + trow, col)), hi = tr_read(tr_addr(tA, kk * 32 + 16 + trow, col));
+                fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int col = wn * 64 + nt * 16 + 4 * lp;
+                s16x4_t lo = tr_read(tr_addr(tB, kk * 32 + trow, col)), hi = tr_read(tr_addr(tB, kk * 32 + 16 + trow, col));
+                fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
         }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const bf16_t* base = sB + buf * BKP * LDB + trow * LDB + wn * 64 + nt * 16 + 4 * lp;
-            s16x4_t lo = tr_read(base), hi = tr_read(base + 16 * LDB);
-            fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-        if (st + 1 < nsteps) store_tiles(buf ^ 1);
         __syncthreads();
     }
+#undef ISSUE_TILE
 
     // slab store: lane holds rows k = 4g+j, column l&15
     float* out = a.slab + (size_t)split * a.K * a.RSC;
@@ -186,7 +182,7 @@ __global__ void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, in
 int pick_mt(int K) {
     int best = 1;
     long bestc = -1;
-    for (int mt = 1; mt <= 5; ++mt) {
+    for (int mt = 1; mt <= 4; ++mt) {
         int bm = 32 * mt;
         long c = (long)cdiv(K, bm) * (bm + 48);
         if (bestc < 0 || c < bestc || (c == bestc && mt > best)) { bestc = c; best = mt; }
@@ -239,7 +235,7 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     if (p.ws > ctx->ws_bytes)
         IFCBK_FAIL(ctx, IFCBK_ENOMEM, "wgrad: workspace %zu > reserved %zu (call ifcbk_ctx_reserve)", p.ws, ctx->ws_bytes);
     WgradArgs a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws; a.zero = (const bf16_t*)ctx->zeros;
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
@@ -251,8 +247,7 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
         case 1: launch<1>(a, p, st); break;
         case 2: launch<2>(a, p, st); break;
         case 3: launch<3>(a, p, st); break;
-        case 4: launch<4>(a, p, st); break;
-        default: launch<5>(a, p, st); break;
+        default: launch<4>(a, p, st); break;
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
     int64_t total = (int64_t)d->K * d->R * d->S * d->Cw;
