@@ -101,7 +101,7 @@ int ifcbk_bn_apply(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const float*
                    const float* shift, const void* residual, int ldr, void* y, void* stream);
 /* dz = dy * (y>0 if relu);  dgamma = sum dz*xhat;  dbeta = sum dz;
  * dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M); if dres!=NULL: dres (+)= dz (residual branch).
- * dy may alias dx.  part_ws: fp32 scratch of ifcbk_bn_bwd_workspace() bytes.                          */
+ * dy may alias dx.  Partial sums go through the ctx workspace (deterministic two-stage reduction).      */
 int ifcbk_bn_bwd(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* y, const void* dy, int lddy,
                  const float* gamma, const float* mean, const float* invstd,
                  void* dx, int lddx, void* dres, int lddres, int dres_accumulate,
