@@ -427,24 +427,14 @@ class Engine:
         [lo, prev_lo) of the flat buffer, so each run's all-reduce can start while later runs compute."""
         if pl.ddp_segs is not None:
             return pl.ddp_segs
+        from .dp import segment_plan
         padded = {o: (n + 3) // 4 * 4 for (o, n, _s, _k, _n) in self.poff.values()}
         ops = pl.bwd_list.ops
-        total = self.nparam_padded
-        target = total / float(nseg)
-        segs, start, prev_lo, lo_min, produced = [], 0, total, total, 0
-        for k, o in enumerate(ops):
-            for off in self._op_param_offsets(o):
-                lo_min = min(lo_min, off)
-                produced += padded[off]
-            last = k == len(ops) - 1
-            closed = produced == total - lo_min          # every tensor at or above lo_min is finished
-            if last:
-                assert closed and lo_min == 0, 'backward list does not cover the flat gradient buffer'
-            if (closed and prev_lo - lo_min >= target) or last:
-                sub = OpList()
-                sub.ops, sub.tags = ops[start:k + 1], pl.bwd_list.tags[start:k + 1]
-                segs.append((Program(sub), lo_min, prev_lo))
-                start, prev_lo = k + 1, lo_min
+        segs = []
+        for (b0, b1, lo, hi) in segment_plan([self._op_param_offsets(o) for o in ops], padded, self.nparam_padded, nseg):
+            sub = OpList()
+            sub.ops, sub.tags = ops[b0:b1], pl.bwd_list.tags[b0:b1]
+            segs.append((Program(sub), b1, lo, hi))
         pl.ddp_segs = segs
         return segs
 
@@ -455,14 +445,8 @@ class Engine:
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
         self.run(pl.fwd_loss)
-        works = []
-        for prog, lo, hi in self.ddp_segments(pl):
-            self.run(prog)
-            if hi > lo:
-                works.append(all_reduce(self.G[lo:hi]))
-        for w in works:
-            if w is not None:
-                w.wait()
+        from .dp import run_overlapped
+        run_overlapped(self.ddp_segments(pl), lambda seg: self.run(seg[0]), self.G, all_reduce)
         self.step_count += 1
         a = pl.adam_pack.arr[0]
         a.i[1] = self.step_count

@@ -185,6 +185,31 @@ class NeustonModel(nn.Module):
         eng.train_step(N)
         return N
 
+    def fit_batch_ddp(self, input_data, input_classes, world, all_reduce):
+        """data-parallel twin of fit_batch: per-rank local BatchNorm statistics (no SyncBN upstream), gradient
+        all-reduce over RCCL launched per finished bucket and overlapped with the rest of backward."""
+        eng = self.model.engine
+        N = eng.load_input_nchw(input_data) if torch.is_tensor(input_data) else eng.load_rois(**input_data)
+        eng.target[:N].copy_(input_classes, non_blocking=True)
+        self.model.train()
+        eng.train_step_ddp(N, world, all_reduce)
+        return N
+
+    def eval_batch(self, input_data, input_classes=None):
+        """fast path of validation_step / test_step (:94-103, :152-157): eval forward -> [CE] -> softmax, all on
+        device, no host sync.  Returns (probs[N,NC] device tensor, loss 0-d device tensor or None)."""
+        eng = self.model.engine
+        N = eng.load_input_nchw(input_data) if torch.is_tensor(input_data) else eng.load_rois(**input_data)
+        self.model.eval()
+        pl = eng.forward_eval(N)
+        loss = None
+        if input_classes is not None:
+            eng.target[:N].copy_(input_classes, non_blocking=True)
+            eng.run(pl.eval_loss)
+            loss = eng.loss[0].clone()
+        eng.run(pl.softmax)
+        return eng.probs[:N].clone(), loss
+
     def epoch_train_loss(self):
         eng = self.model.engine
         v = float(eng.loss_sum.item())

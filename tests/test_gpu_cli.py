@@ -1,0 +1,123 @@
+"""End-to-end drop-in surface on the GPU: ``neuston_net TRAIN`` (BASELINE config 0 shape: resnet18, 2 classes,
+synthetic ROIs as PNG files) then ``RUN --type img`` and ``RUN --type bin`` with the trained .ptl."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(root, per_class=24):
+    from PIL import Image
+    rng = np.random.default_rng(1234)
+    for cls, mean in (('cls_dark', 96), ('cls_bright', 160)):
+        os.makedirs(os.path.join(root, cls))
+        for i in range(per_class):
+            h, w = rng.integers(32, 120, 2)
+            a = np.clip(rng.normal(mean, 32, (h, w)), 0, 255).astype(np.uint8)
+            Image.fromarray(a, 'L').save(os.path.join(root, cls, 'roi_%s_%03d.png' % (cls, i)))
+
+
+def _cli(argv):
+    from ifcb_classifier_amd import neuston_net as nn_
+    args = nn_.argparse_nn().parse_args(argv)
+    nn_.argparse_nn_runtimeparams(args)
+    nn_.main(args)
+    return args
+
+
+def test_train_then_run_img_and_bin(tmp_path, capsys):
+    src = str(tmp_path / 'training-data')
+    os.makedirs(src)
+    _make_dataset(src)
+    outdir = str(tmp_path / 'training-output' / 'smoke')
+    args = _cli(['--batch', '16', '--loaders', '0', 'TRAIN', src, 'resnet18', 'smoke', '--untrain', '--seed', '1',
+                 '--emax', '3', '--emin', '1', '--estop', '0', '--outdir', outdir, '--flip', 'xy',
+                 '--results', 'results.json', 'image_basenames', 'output_scores',
+                 'confusion_matrix', 'f1_macro', '--results', 'results.mat', 'counts_perclass', 'f1_perclass'])
+    for f in ('smoke.ptl', 'epochs.csv', 'args.yml', 'training_images.list', 'validation_images.list', 'results.json',
+              'results.mat'):
+        assert os.path.isfile(os.path.join(outdir, f)), f
+    rows = open(os.path.join(outdir, 'epochs.csv')).read().strip().splitlines()
+    assert rows[0].split(',')[:4] == ['epoch', 'best', 'train_loss', 'val_loss'] and len(rows) == 4
+    tl = [float(r.split(',')[2]) for r in rows[1:]]
+    assert tl[-1] < tl[0], tl                                          # it learns the two brightness classes
+    assert len(open(os.path.join(outdir, 'training_images.list')).read().splitlines()) == 38     # 80:20 of 2x24
+    assert len(open(os.path.join(outdir, 'validation_images.list')).read().splitlines()) == 10
+    res = json.load(open(os.path.join(outdir, 'results.json')))
+    assert res['class_labels'] == ['cls_bright', 'cls_dark'] and len(res['output_scores']) == 10
+    assert np.allclose(np.sum(res['output_scores'], 1), 1.0, atol=1e-4)
+    ck = torch.load(os.path.join(outdir, 'smoke.ptl'), map_location='cpu', weights_only=False)
+    assert ck['hyper_parameters']['model_id'] == 'smoke' and ck['hyper_parameters']['resize'] == 224
+    assert ck['hyper_parameters']['classes'] == ['cls_bright', 'cls_dark']
+    assert list(ck['state_dict'])[0] == 'model.conv1.weight' and tuple(ck['state_dict']['model.conv1.weight'].shape) == (64, 3, 7, 7)
+
+    # ---- RUN --type img
+    run_out = str(tmp_path / 'run-output')
+    _cli(['--batch', '16', '--loaders', '0', 'RUN', src, os.path.join(outdir, 'smoke.ptl'), 'r1', '--type', 'img',
+          '--outdir', run_out + '/{RUN_ID}/v3/{MODEL_ID}', '--outfile', 'img_results.json', '--outfile', 'img_results.mat'])
+    rj = json.load(open(os.path.join(run_out, 'r1', 'v3', 'smoke', 'img_results.json')))
+    assert rj['version'] == 'v3' and rj['model_id'] == 'smoke' and len(rj['input_images']) == 48
+    scores = np.array(rj['output_scores'])
+    assert scores.shape == (48, 2) and np.allclose(scores.sum(1), 1, atol=1e-4)
+    truth = np.array([0 if 'bright' in p else 1 for p in rj['input_images']])
+    assert (np.array(rj['output_classes']) == truth).mean() > 0.8
+    assert os.path.isfile(os.path.join(run_out, 'r1', 'v3', 'smoke', 'img_results.mat'))
+
+    # ---- RUN --type bin on a synthetic raw bin; clobber-skip on the second pass
+    bdir = tmp_path / 'run-data' / 'D2013' / 'D20130526'
+    bdir.mkdir(parents=True)
+    lid = 'D20130526T092352_IFCB013'
+    rng = np.random.default_rng(5)
+    blob, lines, off = b'', [], 0
+    for k in range(21):
+        h, w = (int(v) for v in rng.integers(20, 90, 2))
+        if k == 4:
+            h = w = 0
+        a = np.clip(rng.normal(96 if k % 2 else 160, 30, (h, w)), 0, 255).astype(np.uint8)
+        cols = ['0'] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(off)
+        lines.append(','.join(cols))
+        blob += a.tobytes()
+        off += h * w
+    (bdir / (lid + '.adc')).write_text('\n'.join(lines) + '\n')
+    (bdir / (lid + '.roi')).write_bytes(blob)
+    argv = ['--batch', '8', '--loaders', '0', 'RUN', str(tmp_path / 'run-data'), os.path.join(outdir, 'smoke.ptl'), 'r2',
+            '--outdir', run_out + '/{RUN_ID}/v3/{MODEL_ID}', '--outfile', 'D{BIN_YEAR}/D{BIN_DATE}/{BIN_ID}_class.json']
+    _cli(argv)
+    bj = json.load(open(os.path.join(run_out, 'r2', 'v3', 'smoke', 'D2013', 'D20130526', lid + '_class.json')))
+    assert bj['bin_id'] == lid and bj['roi_numbers'] == [n for n in range(1, 22) if n != 5]
+    assert np.array(bj['output_scores']).shape == (20, 2)
+    odd_dark = np.array(bj['output_classes'])[[i for i, n in enumerate(bj['roi_numbers']) if n % 2 == 0]]
+    assert (odd_dark == 1).mean() > 0.7                                # even target numbers were drawn dark
+    capsys.readouterr()
+    _cli(argv)
+    assert 'already exist - skipping this bin' in capsys.readouterr().out
+
+
+def test_ddp_step_world1_equals_fused_step():
+    """train_step_ddp with a no-op all-reduce and world=1 must produce bitwise the same update as train_step."""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    net = graph.build('resnet18', 3)
+    eng = Engine(net, 0, max_batch=4)
+    eng.init_weights(seed=5)
+    x = torch.rand(4, 3, 224, 224, device='cuda')
+    eng.target[:4].copy_(torch.tensor([0, 1, 2, 1]))
+    p0 = eng.P.clone()
+    eng.load_input_nchw(x)
+    eng.train_step(4)
+    torch.cuda.synchronize()
+    p1, l1 = eng.P.clone(), eng.loss.item()
+    eng.P.copy_(p0); eng.M.zero_(); eng.V.zero_(); eng.step_count = 0; eng.params_changed()
+    eng.RB.zero_()
+    calls = []
+    eng.load_input_nchw(x)
+    eng.train_step_ddp(4, 1, lambda t: calls.append(t.numel()))
+    torch.cuda.synchronize()
+    assert len(calls) >= 2 and sum(calls) == eng.nparam_padded
+    assert eng.loss.item() == l1 and torch.equal(eng.P, p1)

@@ -156,3 +156,110 @@ def test_engine_fails_loudly_without_gpu():
     from ifcb_classifier_amd.neuston_models import get_namebrand_model
     with pytest.raises(RuntimeError, match='HIP device'):
         get_namebrand_model('resnet18', 2)
+
+
+# ---------------------------------------------------------------------------- dataset glue vs the reference
+def _make_tree(root, layout):
+    for cls, n in layout.items():
+        os.makedirs(os.path.join(root, cls))
+        for i in range(n):
+            open(os.path.join(root, cls, 'IFCB_%s_%03d.png' % (cls[:3], i)), 'w').close()
+        open(os.path.join(root, cls, 'notes.txt'), 'w').close()
+
+
+def test_dataset_glue_matches_reference_goldens(tmp_path):
+    """classes / class-min / class-max / class-config csv / split lists equal the outputs of the REFERENCE's own
+    neuston_data.py (captured by tests/golden/make_glue_golden.py) for the same tree, args and seeds."""
+    import random
+    from ifcb_classifier_amd import neuston_data as nd
+    gold = json.load(open(os.path.join(GOLD, 'dataset_glue.json')))
+    for g in gold['imgnorm']:
+        assert [list(x) for x in nd.parse_imgnorm(g['arg'])] == g['result']
+    with pytest.raises(AssertionError, match='img-norm invalid'):
+        nd.parse_imgnorm(['1,2', '3'])
+    root = str(tmp_path / 'tree')
+    os.makedirs(root)
+    _make_tree(root, gold['layout'])
+    rel = lambda p: os.path.relpath(p, root)
+    csvf = os.path.join(root, 'cfg.csv')
+    with open(csvf, 'w') as f:
+        f.write('class,v1\nAkashiwo,1\nBacillaria,0\nCeratium,GROUP\nDitylum,1\nEuglena,GROUP\nmissing_cls,1\n')
+    assert len(gold['datasets']) >= 5
+    for g in gold['datasets']:
+        seed = g['seed']
+        random.seed(1000 + (seed or 0))
+        if g['csv']:
+            ds = nd.NeustonDataset.from_csv(root, csvf, 'v1', minimum_images_per_class=g['class_min'],
+                                            maximum_images_per_class=g['class_max'])
+        else:
+            ds = nd.NeustonDataset(root, minimum_images_per_class=g['class_min'], maximum_images_per_class=g['class_max'])
+        assert ds.classes == g['classes']
+        random.seed(2000 + (seed or 0))
+        if g.get('error'):
+            with pytest.raises(AssertionError):
+                ds.split(g['split'][0], g['split'][1], seed=seed)
+            continue
+        d1, d2 = ds.split(g['split'][0], g['split'][1], seed=seed)
+        assert [list(t) for t in ds.classes_ignored_from_too_few_samples] == g['ignored']
+        assert [rel(p) for p in ds.images] == g['images'] and list(ds.targets) == g['targets']
+        assert ds.count_perclass == g['count_perclass']
+        assert [rel(p) for p in d1.images] == g['train'] and list(d1.targets) == g['train_targets']
+        assert [rel(p) for p in d2.images] == g['val'] and list(d2.targets) == g['val_targets']
+
+
+def test_transform_spec_and_cli_surface():
+    import argparse
+    from ifcb_classifier_amd import neuston_data as nd
+    from ifcb_classifier_amd import neuston_net as nn_
+    a = argparse.Namespace(MODEL='inception_v3', img_norm=['0.5', '0.25'], flip='x+V')
+    tr, va = nd.get_trainval_transforms(a)
+    assert a.resize == 299 and tr.vflip and not tr.hflip and va.vflip and tr.img_norm == ([0.5] * 3, [0.25] * 3)
+    a = argparse.Namespace(MODEL='inception_v3_foo', img_norm=None, flip='xy')
+    tr, va = nd.get_trainval_transforms(a)
+    assert a.resize == 224 and tr.vflip and tr.hflip and not va.vflip and not va.hflip and tr.img_norm is None
+    p = nn_.argparse_nn()
+    t = p.parse_args(['--batch', '32', 'TRAIN', 'src', 'inception_v3', 'id1'])
+    assert (t.batch_size, t.loaders, t.pretrained, t.split, t.class_min, t.emax, t.emin, t.estop, t.seed) == \
+        (32, 4, True, '80:20', 2, 60, 10, 10, 0)
+    assert t.outdir == 'training-output/{TRAIN_ID}' and t.model_id == '{TRAIN_ID}' and t.epochs_log == 'epochs.csv'
+    r = p.parse_args(['RUN', 'src', 'm.ptl', 'rid', '--type', 'img', '--filter', 'IN', 'abc'])
+    assert (r.batch_size, r.src_type, r.outdir, r.clobber, r.filter) == (108, 'img', 'run-output/{RUN_ID}/v3/{MODEL_ID}', False, ['IN', 'abc'])
+
+
+def test_collate_rois_layout():
+    from ifcb_classifier_amd.neuston_data import collate_rois
+    a = np.arange(6, dtype=np.uint8).reshape(2, 3)
+    b = np.arange(20, dtype=np.uint8).reshape(5, 4)
+    batch, tg, paths = collate_rois([((a, 0), 1, 'p0'), ((b, 3), 0, 'p1')])
+    assert batch['in_channels'] == 1 and batch['offs'].tolist() == [0, 6] and batch['hs'].tolist() == [2, 5]
+    assert batch['ws'].tolist() == [3, 4] and batch['flips'].tolist() == [0, 3] and (batch['max_h'], batch['max_w']) == (5, 4)
+    assert batch['pixels'].tolist() == list(range(6)) + list(range(20)) and tg.tolist() == [1, 0] and paths == ['p0', 'p1']
+    c = np.zeros((2, 2, 3), np.uint8)
+    batch, ids = collate_rois([((a, 0), 'x'), ((c, 0), 'y')])
+    assert batch['in_channels'] == 3 and batch['offs'].tolist() == [0, 18] and batch['pixels'].numel() == 18 + 12
+
+
+def test_ifcb_bin_reader_and_pid(tmp_path):
+    from ifcb_classifier_amd.ifcb_bins import DataDirectory, Pid
+    d = tmp_path / 'D2013' / 'D20130526'
+    d.mkdir(parents=True)
+    lid = 'D20130526T092352_IFCB013'
+    rois = [np.full((3, 4), 7, np.uint8), np.zeros((0, 0), np.uint8), np.arange(10, dtype=np.uint8).reshape(2, 5)]
+    blob, lines, off = b'', [], 0
+    for r in rois:
+        h, w = r.shape
+        cols = ['0'] * 24
+        cols[13], cols[14], cols[15], cols[16], cols[17] = '1', '2', str(w), str(h), str(off)
+        lines.append(','.join(cols))
+        blob += r.tobytes()
+        off += h * w
+    (d / (lid + '.adc')).write_text('\n'.join(lines) + '\n')
+    (d / (lid + '.roi')).write_bytes(blob)
+    bins = list(DataDirectory(str(tmp_path)))
+    assert len(bins) == 1 and bins[0].pid.pid == lid and bins[0].pid.year == '2013' and bins[0].pid.yearday == '20130526'
+    imgs = bins[0].images
+    assert sorted(imgs) == [1, 3] and np.array_equal(imgs[3], rois[2]) and imgs[1].shape == (3, 4)
+    assert bins[0].pid.with_target(3).pid == lid + '_00003' and bins[0].pid.with_target(3).target == 3
+    old = Pid('IFCB1_2010_025_134132')
+    assert (old.year, old.yearday, old.schema) == ('2010', '2010_025', 'v1')
+    assert list(DataDirectory(str(tmp_path), blacklist=['IFCB013'])) == []
