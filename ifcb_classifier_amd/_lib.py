@@ -74,7 +74,7 @@ _PROTOS = {
     'ifcbk_bn_finalize': (_i, [_vp, C.POINTER(BnDesc), _vp, _i] + [_vp] * 9),
     'ifcbk_bn_apply': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'ifcbk_bn_bwd': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp,
-                          _i, _vp]),
+                          _i, _vp, _vp, _vp]),
     'ifcbk_maxpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _vp]),
     'ifcbk_maxpool_bwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_avgpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp]),

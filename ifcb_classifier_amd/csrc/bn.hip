@@ -45,6 +45,29 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
     }
 }
 
+// stage 0 for layers with many M-blocks: chunk `blockIdx.y` of the partial rows -> one fp32 row (double accumulate)
+__global__ __launch_bounds__(256) void bn_prereduce_kernel(const float* part, int mblocks, int C, int rows_per_chunk,
+                                                           float* out) {
+    __shared__ double s[2][4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + c;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(r0 + rows_per_chunk, mblocks);
+    double a = 0.0, b = 0.0;
+    if (ch < C)
+        for (int mb = r0 + rg; mb < r1; mb += 4) {
+            a += (double)part[((size_t)mb * 2 + 0) * C + ch];
+            b += (double)part[((size_t)mb * 2 + 1) * C + ch];
+        }
+    s[0][rg][c] = a;
+    s[1][rg][c] = b;
+    __syncthreads();
+    if (rg == 0 && ch < C) {
+        out[((size_t)blockIdx.y * 2 + 0) * C + ch] = (float)((s[0][0][c] + s[0][1][c]) + (s[0][2][c] + s[0][3][c]));
+        out[((size_t)blockIdx.y * 2 + 1) * C + ch] = (float)((s[1][0][c] + s[1][1][c]) + (s[1][2][c] + s[1][3][c]));
+    }
+}
+
 __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* beta, const float* rmean,
                                      const float* rvar, float* scale, float* shift, float eps) {
     int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,10 +111,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* x, int ldx,
 // ---------------------------------------------------------------- backward
 // pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks (64 channels) x 32 rows in flight
 constexpr int BWD_ROWS = 1024;
-template <bool RELU>
+// MASK: 0 = no ReLU, 1 = ReLU mask read from y (residual case), 2 = ReLU mask recomputed as x*scale+shift > 0
+// (bit-identical to what bn_apply rounded: same expression, sign survives bf16 rounding) -- saves the y read
+template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
                                                              const bf16_t* dy, int lddy, const float* mean,
-                                                             const float* invstd, float* part, int64_t M, int C) {
+                                                             const float* invstd, const float* scale, const float* shift,
+                                                             float* part, int64_t M, int C) {
     __shared__ float red[4][2][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cc = t & 7, r0 = t >> 3;
@@ -102,20 +128,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* x, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) sb[j] = sg[j] = 0.f;
     if (c < C) {
-        float mu[8], is[8];
+        float mu[8], is[8], sc[8], sh[8];
         *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(mean + c);
         *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(mean + c + 4);
         *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(invstd + c);
         *reinterpret_cast<float4*>(is + 4) = *reinterpret_cast<const float4*>(invstd + c + 4);
+        if (MASK == 2) {
+            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + c);
+            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
+            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + c);
+            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + c + 4);
+        }
         for (int64_t m = mbeg + r0; m < mend; m += 32) {
             float fx[8], fy[8], fd[8];
             unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
             unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
-            if (RELU) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
+            if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float dz = fd[j];
-                if (RELU) dz = fy[j] > 0.f ? dz : 0.f;
+                if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
+                if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
                 sb[j] += dz;
                 sg[j] += dz * ((fx[j] - mu[j]) * is[j]);
             }
@@ -175,10 +208,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
 }
 
 // pass 3: dx (and the residual branch gradient)
-template <bool RELU>
+template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
                                                          const bf16_t* dy, int lddy, const float* gamma,
-                                                         const float* mean, const float* invstd, const float* tmp,
+                                                         const float* mean, const float* invstd, const float* scale,
+                                                         const float* shift, const float* tmp,
                                                          bf16_t* dx, int lddx, bf16_t* dres, int lddres, int dres_acc,
                                                          int64_t M, int C, float invM) {
     const int cpr = C / 8;
@@ -189,11 +223,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx
     float fx[8], fy[8], fd[8], o[8];
     unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
     unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
-    if (RELU) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
+    if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float dz = fd[j];
-        if (RELU) dz = fy[j] > 0.f ? dz : 0.f;
+        if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
+        if (MASK == 2) dz = (fx[j] * scale[c + j] + shift[c + j]) > 0.f ? dz : 0.f;
         fd[j] = dz;
         float is = invstd[c + j];
         float xhat = (fx[j] - mean[c + j]) * is;
@@ -222,6 +257,18 @@ extern "C" int ifcbk_bn_finalize(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const f
     if (part) {
         double M = (double)d->M;
         double unbias = d->M > 1 ? M / (M - 1.0) : 1.0;
+        if (mblocks > 512) {
+            // two-stage: 64-row chunks are pre-reduced by many blocks into the ctx workspace
+            const int rpc = 64;
+            int nchunk = cdiv(mblocks, rpc);
+            size_t need = (size_t)nchunk * 2 * d->C * sizeof(float);
+            if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_finalize: workspace %zu > reserved %zu", need, ctx->ws_bytes);
+            hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(d->C, 64), nchunk), dim3(256), 0, st, part, mblocks, d->C, rpc,
+                               (float*)ctx->ws);
+            IFCBK_LAUNCH_CHECK(ctx, "bn_prereduce");
+            part = (const float*)ctx->ws;
+            mblocks = nchunk;
+        }
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d->C, 16)), dim3(1024), 0, st, part, mblocks, d->C, 1.0 / M,
                            unbias, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, d->eps,
                            d->momentum);
@@ -254,7 +301,7 @@ extern "C" int ifcbk_bn_apply(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void
 extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy,
                             int lddy, const float* gamma, const float* mean, const float* invstd, void* dx, int lddx,
                             void* dres, int lddres, int dres_accumulate, float* dgamma, float* dbeta,
-                            int param_accumulate, void* stream) {
+                            int param_accumulate, const float* scale, const float* shift, void* stream) {
     if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: bad desc");
     const int C = d->C;
     const int64_t M = d->M;
@@ -266,15 +313,20 @@ extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* 
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* xx = (const bf16_t*)x; const bf16_t* yy = (const bf16_t*)y; const bf16_t* dd = (const bf16_t*)dy;
     dim3 g1(ntiles, cdiv(C, 64));
-    if (d->relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, part, M, C);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, part, M, C);
+    // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
+    const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
+    if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
+    if (mask == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
     int64_t total = M * (C / 8);
     float invM = (float)(1.0 / (double)M);
-    if (d->relu) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
-    else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    else hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
     return 0;
 }

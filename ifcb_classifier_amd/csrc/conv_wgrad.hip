@@ -165,18 +165,35 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
         }
 }
 
-// dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]
-__global__ void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw, int accumulate) {
-    int64_t total = (int64_t)K * RS * Cw;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int cw = (int)(i % Cw);
-    int64_t krs = i / Cw;
-    int64_t src = krs * C + cw;
-    int64_t stride = (int64_t)K * RS * C;
+// dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]; 64 outputs x 4 split lanes per block, the 4 lane sums are
+// combined in a fixed order (bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw,
+                                                    int accumulate) {
+    __shared__ float part[4][64];
+    const int64_t total = (int64_t)K * RS * Cw;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * stride + src];
-    dw[i] = accumulate ? dw[i] + s : s;
+    if (i < total) {
+        int cw = (int)(i % Cw);
+        int64_t krs = i / Cw;
+        const float* src = slab + krs * C + cw;
+        const int64_t stride = (int64_t)K * RS * C;
+        float s0 = 0.f, s1 = 0.f;
+        int sp = sg;
+        for (; sp + 4 < nsplit; sp += 8) {
+            s0 += src[sp * stride];
+            s1 += src[(sp + 4) * stride];
+        }
+        if (sp < nsplit) s0 += src[sp * stride];
+        s = s0 + s1;
+    }
+    part[sg][o] = s;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        float r = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        dw[i] = accumulate ? dw[i] + r : r;
+    }
 }
 
 int pick_mt(int K) {
@@ -251,7 +268,7 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
     int64_t total = (int64_t)d->K * d->R * d->S * d->Cw;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)ctx->ws, dw, p.nsplit,
+    hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 64)), dim3(256), 0, st, (const float*)ctx->ws, dw, p.nsplit,
                        d->K, d->R * d->S, d->C, d->Cw, accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return 0;

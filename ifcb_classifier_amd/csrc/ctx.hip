@@ -70,7 +70,7 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
         case IFCBK_OP_BN_BWD:
             return ifcbk_bn_bwd(c, &o->u.bn, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
                                 (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc, (float*)p[8], (float*)p[9],
-                                pacc, st);
+                                pacc, (const float*)p[10], (const float*)p[11], st);
         case IFCBK_OP_MAXPOOL_FWD: return ifcbk_maxpool_fwd(c, &o->u.pool, p[0], p[1], (uint8_t*)p[2], st);
         case IFCBK_OP_MAXPOOL_BWD: return ifcbk_maxpool_bwd(c, &o->u.pool, p[0], (const uint8_t*)p[1], p[2], acc, st);
         case IFCBK_OP_AVGPOOL_FWD: return ifcbk_avgpool_fwd(c, &o->u.pool, p[0], p[1], st);

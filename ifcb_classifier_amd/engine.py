@@ -356,7 +356,7 @@ class Engine:
                 bwd.add(_lib.OP_BN_BWD, n.name,
                         p=(_vp(self.act[n.raw.id]), self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
                            self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
-                           self._pptr(bkey + '.bias', 'G')),
+                           self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
                         i=(n.y.buf.C, n.K, lddres), flags=dres_acc, bn=bnd)
                 dbw = ConvDesc.from_buffer_copy(d)
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch

@@ -105,7 +105,9 @@ int ifcbk_bn_apply(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const float*
 int ifcbk_bn_bwd(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* y, const void* dy, int lddy,
                  const float* gamma, const float* mean, const float* invstd,
                  void* dx, int lddx, void* dres, int lddres, int dres_accumulate,
-                 float* dgamma, float* dbeta, int param_accumulate, void* stream);
+                 float* dgamma, float* dbeta, int param_accumulate,
+                 const float* scale, const float* shift /* nullable: bn_apply's affine; lets the ReLU mask be
+                 recomputed from x (y is then not read) when there is no residual */, void* stream);
 
 /* ------------------------------------------------------------------ pooling
  * replaces F.max_pool2d / F.avg_pool2d(count_include_pad=True) / adaptive_avg_pool2d in [TV] graphs  */

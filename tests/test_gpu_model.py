@@ -127,7 +127,7 @@ def test_fused_step_equals_autograd_surface_and_adam_oracle():
     pn, mn, vn = O.adam_step(p0.cpu(), g_ref.cpu(), torch.zeros_like(p0).cpu(), torch.zeros_like(p0).cpu(), 1)
     assert rel(eng.P.cpu(), pn) < 1e-6
     assert (eng.P.cpu() - pn).abs().max().item() < 1e-6
-    assert rel(eng.M.cpu(), mn) < 1e-6 and rel(eng.V.cpu(), vn) < 1e-5
+    assert rel(eng.M.cpu(), mn) < 1e-6 and rel(eng.V.cpu(), vn) < 5e-5    # fma contraction vs addcmul_
     assert abs(m.epoch_train_loss() - loss_ref) < 1e-5 * max(1, abs(loss_ref))
 
 

@@ -163,7 +163,7 @@ def test_bn_fwd_bwd_vs_oracle(ctx, N, Cc, H, W, ld, relu, res):
     dgam, dbet = torch.zeros(Cc).cuda(), torch.zeros(Cc).cuda()
     ctx.call('ifcbk_bn_bwd', C.byref(d), _lib.ptr(rawd), _lib.ptr(yd), _lib.ptr(gyd), ld, _lib.ptr(gamma_d),
              _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(dx), Cc, _lib.ptr(dresd), Cc, 0, _lib.ptr(dgam),
-             _lib.ptr(dbet), 0, st)
+             _lib.ptr(dbet), 0, _lib.ptr(stats[2]), _lib.ptr(stats[3]), st)
     torch.cuda.synchronize()
     assert torch.allclose(dgam.cpu(), dg, rtol=2e-4, atol=2e-4 * dg.abs().max().item())
     assert torch.allclose(dbet.cpu(), db, rtol=2e-4, atol=2e-4 * db.abs().max().item())
