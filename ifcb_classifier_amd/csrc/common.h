@@ -81,5 +81,16 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const fastdiv_t& f) {
 }
 
 int ifcbk_conv_fwd_nt(int K);
+int ifcbk_conv_fwd_wm(int M, int K);
 int ifcbk_conv_wgrad_mt(int K);
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Bijective remap of the linear
+// block id so that every XCD works on ONE contiguous range of logical tiles: neighbouring tiles (which share
+// input rows / operand panels) then hit the same L2.  Speed only -- any placement is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -14,6 +14,7 @@
 // through LDS as whole 16-byte chunks (coalesced rows) and the BatchNorm batch statistics (sum, sum of
 // squares of the ROUNDED outputs) are reduced in the same pass -- no extra read of the conv output.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -22,7 +23,7 @@ struct ConvArgs {
     const bf16_t* w;
     bf16_t* y;
     float* part;       // [mblocks][2][K] or null
-    const bf16_t* zero;   // >= 16 bytes of zeros (source of padded / out-of-range chunks)
+    unsigned xbytes, wbytes;   // buffer-descriptor extents of x and w
     int H, W, C, ldx;
     int K, R, S;
     int P, Q, ldy;
@@ -33,9 +34,7 @@ struct ConvArgs {
     int tilesN;
 };
 
-constexpr int BM = 128;
 constexpr int BK = 64;
-constexpr int NTHREADS = 256;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -48,66 +47,87 @@ __device__ __forceinline__ const bf16x8_t* frag_ptr(const bf16_t* tile, int row,
     return reinterpret_cast<const bf16x8_t*>(tile + row * BK + ((chunk ^ (row & 7)) << 3));
 }
 
-template <int NT>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NT: 16-column tiles per wave in N (block N = 32*NT); WM: waves along M (block M = 64*WM, threads = 128*WM);
+// NSTAGE: LDS ring depth (NSTAGE-1 tiles of LDS-DMA in flight across the per-step barrier, counted vmcnt).
+template <int NT, int WM, int NSTAGE, bool STRIDED>
+__global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
+    constexpr int NW = 2 * WM;
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int BM = 64 * WM;
     constexpr int BN = 32 * NT;
+    constexpr int JB = (NT * 4 + NW - 1) / NW;         // B-tile LDS-DMA instructions per wave per tile
+    constexpr int G = 4 + JB;                          // LDS-DMA instructions per wave per tile
+    constexpr int D = NSTAGE - 1;                      // prefetch distance (tiles)
     constexpr int CPR = BN / 8;                        // 16-byte chunks per output row
     constexpr int CPRP = CPR <= 4 ? 4 : CPR <= 8 ? 8 : CPR <= 16 ? 16 : 32;
     constexpr int LDC = BN + 8;                        // C-tile row stride (elements)
     constexpr int STAGE = (BM + BN) * BK;              // elements per pipeline stage
-    constexpr int STAGE_BYTES = 2 * STAGE * 2;
-    constexpr int CT_BYTES = BM * LDC * 2;
+    constexpr int STAGE_BYTES = NSTAGE * STAGE * 2;
+    constexpr int CT_BYTES = BM * LDC * 2 + NW * BN * 2 * 4;
     constexpr int MAIN_BYTES = STAGE_BYTES > CT_BYTES ? STAGE_BYTES : CT_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 4 * BN * 2 * 4];
-    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem);             // [2][A: BM*BK | B: BN*BK]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 1024];
+    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem);             // [NSTAGE][A: BM*BK | B: BN*BK]
     bf16_t* sC = reinterpret_cast<bf16_t*>(smem);                 // [BM][LDC] (epilogue)
-    float* sRed = reinterpret_cast<float*>(smem + MAIN_BYTES);    // [4][2][BN]
+    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * 2);  // [NW][2][BN] (epilogue)
+    bf16_t* sDummy = reinterpret_cast<bf16_t*>(smem + MAIN_BYTES); // sink of the padding LDS-DMA (uniform vmcnt)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int bid = blockIdx.x;
+    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = bid / a.tilesN, ntile = bid - mtile * a.tilesN;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
-    // ---- LDS-DMA roles: one wave-instruction fills 8 tile rows (1 KiB); lane -> (row l>>3, phys chunk l&7)
+    // ---- LDS-DMA roles: one wave-instruction fills 8 tile rows (1 KiB); lane -> (row l>>3, phys chunk l&7).
+    // Loads are buffer_load ... lds through two SRDs: the hardware range check turns the out-of-range offset given to
+    // padded / strided-out / tail chunks into zeros, so the gather needs no zero page, no 64-bit address math and no
+    // branches -- per row and k-step: two adds, two unsigned compares, one add, one select.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     const int lrow8 = lane >> 3;
     const int csrc = (lane & 7) ^ lrow8;               // logical 16-byte chunk this lane fetches, every row group
-    const bf16_t* xrow[4];
-    int bh[4], bw[4];
-    bool rvalid[4];
+    int off0[4], bh[4], bw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int m = m0 + (wave * 4 + j) * 8 + lrow8;
-        rvalid[j] = m < a.M;
-        int mm = rvalid[j] ? m : 0;
+        bool rv = m < a.M;
+        int mm = rv ? m : 0;
         int n = mm / a.PQ;
         int rem = mm - n * a.PQ;
         int p = rem / a.Q;
         int q = rem - p * a.Q;
-        bh[j] = p * a.ostr_h + a.base_h;
+        bh[j] = rv ? p * a.ostr_h + a.base_h : -(1 << 24);       // rows past M never pass the range check
         bw[j] = q * a.ostr_w + a.base_w;
-        xrow[j] = a.x + (size_t)n * a.H * a.W * a.ldx;
+        off0[j] = STRIDED ? n * a.H * a.W * a.ldx : ((n * a.H + bh[j]) * a.W + bw[j]) * a.ldx;
     }
-    int kc, kr, ks;
+    int kc, kr, ks, tapoff;
     {
         int k = csrc * 8;
         int rs = k / a.C;
         kc = k - rs * a.C;
         kr = rs / a.S;
         ks = rs - kr * a.S;
+        tapoff = (kr * a.W + ks) * a.ldx + kc;
     }
-    const bf16_t* wrow[NT];
-    bool nvalid[NT];
+    unsigned woff[JB];
+    bool gvalid[JB];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        int n = n0 + (j * 4 + wave) * 8 + lrow8;
-        nvalid[j] = n < a.K;
-        wrow[j] = a.w + (size_t)(nvalid[j] ? n : 0) * a.Kg + csrc * 8;
+    for (int j = 0; j < JB; ++j) {
+        int grp = j * NW + wave;
+        gvalid[j] = grp < NT * 4;
+        int n = n0 + grp * 8 + lrow8;
+        woff[j] = (gvalid[j] && n < a.K) ? (unsigned)(n * a.Kg + csrc * 8) * 2u : OOB;
     }
     const int nk = (a.Kg + BK - 1) / BK;
     const int hmask = (1 << a.ish) - 1, wmask = (1 << a.isw) - 1;
+    const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
 
 #define ISSUE_TILE(kt, stage)                                                                              \
     {                                                                                                      \
@@ -116,21 +136,31 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
         const bool kvalid = kr < a.R;                                                                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
             int hr = bh[j] + kr, wr = bw[j] + ks;                                                          \
-            bool v = rvalid[j] && kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0); \
-            int hi = hr >> a.ish, wi = wr >> a.isw;                                                        \
-            v = v && hi < a.H && wi < a.W;                                                                 \
-            const bf16_t* src = v ? xrow[j] + ((size_t)hi * a.W + wi) * a.ldx + kc : a.zero;              \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, 0, 0); \
+            unsigned voff;                                                                                 \
+            if (STRIDED) {                                                                                 \
+                bool v = kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0);       \
+                int hi = hr >> a.ish, wi = wr >> a.isw;                                                    \
+                v = v && hi < a.H && wi < a.W;                                                             \
+                voff = v ? (unsigned)(off0[j] + (hi * a.W + wi) * a.ldx + kc) * 2u : OOB;                  \
+            } else {                                                                                       \
+                bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;           \
+                voff = v ? (unsigned)(off0[j] + tapoff) * 2u : OOB;                                        \
+            }                                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, voff, 0, 0, 0); \
         }                                                                                                  \
         const bool kv2 = ((kt) * BK + csrc * 8) < a.Kg;                                                    \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
-            const bf16_t* src = (nvalid[j] && kv2) ? wrow[j] + (size_t)(kt) * BK : a.zero;                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dstB + (j * 4 + wave) * 8 * BK), 16, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                                   \
+            unsigned voff = kv2 ? woff[j] + (unsigned)(kt) * (BK * 2) : OOB;                               \
+            voff = woff[j] == OOB ? OOB : voff;                                                            \
+            bf16_t* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff, 0, 0, 0);                 \
         }                                                                                                  \
         kc += BK;                                                                                          \
+        tapoff += BK;                                                                                      \
         while (kc >= a.C) {                                                                                \
             kc -= a.C;                                                                                     \
-            if (++ks == a.S) { ks = 0; ++kr; }                                                             \
+            tapoff += a.ldx - a.C;                                                                         \
+            if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                                \
         }                                                                                                  \
     }
 
@@ -140,31 +170,52 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    ISSUE_TILE(0, 0)
-    __syncthreads();            // hipcc drains vmcnt(0) before the barrier: tile 0 has landed for every wave
+    // prologue: D tiles in flight
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nk) ISSUE_TILE(d, d)
 
     const int frow = lane & 15, fchunk = lane >> 4;
+    // fragment addresses: the swizzle term depends only on (frow & 7, fchunk, kk); m/n tiles are immediates
+    const bf16_t* fA[2];
+    const bf16_t* fB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) << 3;
+        fA[kk] = sStage + (wm * 64 + frow) * BK + ph;
+        fB[kk] = sStage + BM * BK + (wn * (NT * 16) + frow) * BK + ph;
+    }
+    int stage = 0;                // stage holding tile kt
+    int istage = D % NSTAGE;      // stage the next issue goes to
     for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) ISSUE_TILE(kt + 1, stage ^ 1)
-        const bf16_t* tA = sStage + stage * STAGE;
-        const bf16_t* tB = tA + BM * BK;
+        // tile kt has landed once all but the tiles issued after it are done (counted, never a full drain mid-loop)
+        const int newer = nk - 1 - kt < D - 1 ? nk - 1 - kt : D - 1;
+        if (D >= 3 && newer >= 2) wait_vmcnt<2 * G>();
+        else if (D >= 2 && newer >= 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // every wave's share of tile kt is in LDS; stage (kt-1) is no longer read
+        if (kt + D < nk) ISSUE_TILE(kt + D, istage)
+        const int soff = stage * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fa[4], fb[NT];
+            const bf16_t* pa = fA[kk] + soff;
+            const bf16_t* pb = fB[kk] + soff;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = *frag_ptr(tA, wm * 64 + mt * 16 + frow, kk * 4 + fchunk);
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(pa + mt * 16 * BK);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fb[nt] = *frag_ptr(tB, wn * (NT * 16) + nt * 16 + frow, kk * 4 + fchunk);
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(pb + nt * 16 * BK);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
         }
-        __syncthreads();        // next tile landed (vmcnt(0) drained) and this stage is free to refill
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+        istage = istage + 1 == NSTAGE ? 0 : istage + 1;
     }
 #undef ISSUE_TILE
+    __syncthreads();            // all stages drained and consumed: the epilogue reuses the ring as the C tile
 
     // ---- epilogue: acc -> bf16 C tile in LDS (lane: 4 consecutive channels of one pixel)
     {
@@ -236,8 +287,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_bf16(ConvArgs a) {
             for (int i = t; i < 2 * BN; i += NTHREADS) {
                 int which = i / BN, n = i - which * BN;
                 if (n0 + n < a.K) {
-                    float s = sRed[(0 * 2 + which) * BN + n] + sRed[(1 * 2 + which) * BN + n] +
-                              sRed[(2 * 2 + which) * BN + n] + sRed[(3 * 2 + which) * BN + n];
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s += sRed[(w * 2 + which) * BN + n];
                     a.part[((size_t)mtile * 2 + which) * a.K + n0 + n] = s;
                 }
             }
@@ -265,27 +317,52 @@ int check_desc(ifcbk_ctx* ctx, const ifcbk_conv_desc* d) {
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: stride must be 1 or 2");
     int P = (d->H + 2 * d->pad_h - d->R) / d->stride_h + 1, Q = (d->W + 2 * d->pad_w - d->S) / d->stride_w + 1;
     if (P != d->P || Q != d->Q) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: P,Q=%d,%d inconsistent (expect %d,%d)", d->P, d->Q, P, Q);
-    if ((int64_t)d->N * d->P * d->Q >= (1ll << 31) || (int64_t)d->N * d->H * d->W >= (1ll << 31))
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: pixel count exceeds 2^31");
+    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31))
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: a tensor exceeds the 2 GiB buffer-descriptor window");
     return 0;
 }
 
-template <int NT>
-void launch(const ConvArgs& a, int tilesM, hipStream_t st) {
-    hipLaunchKernelGGL(conv_igemm_bf16<NT>, dim3((unsigned)(tilesM * a.tilesN)), dim3(NTHREADS), 0, st, a);
+// block-M choice: 256-pixel tiles (8 waves, 3-stage ring, 1 block/CU) when they still fill the chip several times
+// over; otherwise 128-pixel tiles (4 waves, 2-stage ring, 2 blocks/CU) for the small-M layers
+int pick_wm(int M, int K) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("IFCBK_CONV_WM"); force = e ? atoi(e) : 0; }
+    if (force == 2 || force == 4) return force;
+    int nt = pick_nt(K);
+    long tiles256 = (long)cdiv(M, 256) * cdiv(K, 32 * nt);
+    (void)tiles256;
+    return 2;   // measured: 128-pixel tiles with 2 blocks/CU beat 256-pixel tiles on every inception layer (r1)
+}
+
+template <int NT, int WM, int NSTAGE>
+void launch(const ConvArgs& a, hipStream_t st) {
+    int tilesM = cdiv(a.M, 64 * WM);
+    dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
+    if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm_bf16<NT, WM, NSTAGE, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16<NT, WM, NSTAGE, false>), grid, block, 0, st, a);
 }
 
 int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
     int nt = pick_nt(a.K);
+    int wm = pick_wm(a.M, a.K);
     a.tilesN = cdiv(a.K, 32 * nt);
-    int tilesM = cdiv(a.M, BM);
-    if ((int64_t)tilesM * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
-    switch (nt) {
-        case 1: launch<1>(a, tilesM, st); break;
-        case 2: launch<2>(a, tilesM, st); break;
-        case 3: launch<3>(a, tilesM, st); break;
-        case 4: launch<4>(a, tilesM, st); break;
-        default: launch<5>(a, tilesM, st); break;
+    if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
+    if (wm == 4) {
+        switch (nt) {
+            case 1: launch<1, 4, 3>(a, st); break;
+            case 2: launch<2, 4, 3>(a, st); break;
+            case 3: launch<3, 4, 3>(a, st); break;
+            case 4: launch<4, 4, 3>(a, st); break;
+            default: launch<5, 4, 3>(a, st); break;
+        }
+    } else {
+        switch (nt) {
+            case 1: launch<1, 2, 2>(a, st); break;
+            case 2: launch<2, 2, 2>(a, st); break;
+            case 3: launch<3, 2, 2>(a, st); break;
+            case 4: launch<4, 2, 2>(a, st); break;
+            default: launch<5, 2, 2>(a, st); break;
+        }
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_igemm_bf16");
     return 0;
@@ -295,13 +372,19 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
 
 int ifcbk_conv_fwd_nt(int K) { return pick_nt(K); }
 
-extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) { return cdiv((int64_t)d->N * d->P * d->Q, BM); }
+int ifcbk_conv_fwd_wm(int M, int K) { return pick_wm(M, K); }
+
+extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
+    int M = d->N * d->P * d->Q;
+    return cdiv(M, 64 * pick_wm(M, d->K));
+}
 
 extern "C" int ifcbk_conv2d_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y,
                                 float* bn_part, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
     ConvArgs a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part; a.zero = (const bf16_t*)ctx->zeros;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part;
+    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S;
     a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
@@ -316,7 +399,8 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     if (int e = check_desc(ctx, d)) return e;
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
-    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr; a.zero = (const bf16_t*)ctx->zeros;
+    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr;
+    a.xbytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
     a.H = d->P; a.W = d->Q; a.C = d->K; a.ldx = d->ldy;
     a.K = d->C; a.R = d->R; a.S = d->S;
     a.P = d->H; a.Q = d->W; a.ldy = d->ldx;

@@ -25,6 +25,7 @@ struct WgradArgs {
     int RSC;
     int split_len;    // pixels per split (multiple of BKP)
     int tilesN;       // column tiles
+    int tiles;        // tilesM * tilesN
     fastdiv_t fPQ, fQ;
 };
 
@@ -57,10 +58,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
+    // 1-D grid, split-major: all tiles of one pixel range sit on one XCD (they re-read the same pixels)
+    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / a.tiles;
+    const int tile = lin - split * a.tiles;
     const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
     const int k0 = mtile * BMW, n0 = ntile * BNW;
-    const int split = blockIdx.y;
     const int pix_begin = split * a.split_len;
     const int pix_end = min(pix_begin + a.split_len, a.M);
 
@@ -232,7 +235,7 @@ Plan make_plan(const ifcbk_conv_desc* d) {
 
 template <int MT>
 void launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
-    hipLaunchKernelGGL(conv_wgrad_bf16<MT>, dim3(p.tilesM * p.tilesN, p.nsplit), dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL(conv_wgrad_bf16<MT>, dim3(p.tilesM * p.tilesN * p.nsplit), dim3(NTHREADS), 0, st, a);
 }
 
 }  // namespace
@@ -257,7 +260,7 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     a.K = d->K; a.R = d->R; a.S = d->S; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.M = d->N * d->P * d->Q; a.RSC = d->R * d->S * d->C;
-    a.split_len = p.split_len; a.tilesN = p.tilesN;
+    a.split_len = p.split_len; a.tilesN = p.tilesN; a.tiles = p.tilesM * p.tilesN;
     a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
     hipStream_t st = (hipStream_t)stream;
     switch (p.mt) {

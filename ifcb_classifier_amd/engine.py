@@ -196,7 +196,7 @@ class Engine:
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
         max_raw = max(n.P * n.Q * n.K for n in self.convs)
         self.draw = torch.zeros(N * max_raw, dtype=bf, device=dev)
-        mb = max(((N * n.P * n.Q + 127) // 128) * 2 * n.K for n in self.convs)
+        mb = max(self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs)
         self.bn_part = torch.zeros(mb, dtype=torch.float32, device=dev)
         self.argmax = {}
         for k, n in enumerate(net.nodes):
@@ -275,7 +275,7 @@ class Engine:
                 wk = _vp(self.Wsh, 2 * n.w_off)
                 wT = _vp(self.Wsh, 2 * n.wT_off)
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
-                mb = (M + 127) // 128
+                mb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
                 bnd = BnDesc(M, n.K, n.K, n.y.buf.C, 1 if n.relu else 0, _lib.BF16, n.eps, 0.1)
                 res = self._aptr(n.residual) if n.residual is not None else None
                 ldr = n.residual.buf.C if n.residual is not None else 0
