@@ -32,6 +32,7 @@ struct ConvArgs {
     int accumulate;
     int PQ;
     int tilesN;
+    fastdiv_t fPQ, fQ;
 };
 
 constexpr int BK = 64;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
     constexpr int STAGE_BYTES = NSTAGE * STAGE * 2;
     constexpr int CT_BYTES = BM * LDC * 2 + NW * BN * 2 * 4;
     constexpr int MAIN_BYTES = STAGE_BYTES > CT_BYTES ? STAGE_BYTES : CT_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + 1024];
+    constexpr int DUMMY_BYTES = (JB * NW > NT * 4) ? 1024 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + DUMMY_BYTES];
     bf16_t* sStage = reinterpret_cast<bf16_t*>(smem);             // [NSTAGE][A: BM*BK | B: BN*BK]
     bf16_t* sC = reinterpret_cast<bf16_t*>(smem);                 // [BM][LDC] (epilogue)
     float* sRed = reinterpret_cast<float*>(smem + BM * LDC * 2);  // [NW][2][BN] (epilogue)
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
         int m = m0 + (wave * 4 + j) * 8 + lrow8;
         bool rv = m < a.M;
         int mm = rv ? m : 0;
-        int n = mm / a.PQ;
+        int n = (int)fdiv((uint32_t)mm, a.fPQ);
         int rem = mm - n * a.PQ;
-        int p = rem / a.Q;
+        int p = (int)fdiv((uint32_t)rem, a.fQ);
         int q = rem - p * a.Q;
         bh[j] = rv ? p * a.ostr_h + a.base_h : -(1 << 24);       // rows past M never pass the range check
         bw[j] = q * a.ostr_w + a.base_w;
@@ -109,11 +111,14 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
     }
     int kc, kr, ks, tapoff;
     {
-        int k = csrc * 8;
-        int rs = k / a.C;
-        kc = k - rs * a.C;
-        kr = rs / a.S;
-        ks = rs - kr * a.S;
+        // csrc*8 < 64: a short subtract loop instead of two integer divisions
+        kc = csrc * 8;
+        kr = 0;
+        ks = 0;
+        while (kc >= a.C) {
+            kc -= a.C;
+            if (++ks == a.S) { ks = 0; ++kr; }
+        }
         tapoff = (kr * a.W + ks) * a.ldx + kc;
     }
     unsigned woff[JB];
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
 int pick_nt(int K) {
     int best = 1;
     long bestc = -1;
-    for (int nt = 1; nt <= 5; ++nt) {
+    for (int nt = 1; nt <= 6; ++nt) {
         int bn = 32 * nt;
         long c = (long)cdiv(K, bn) * (bn + 48);
         if (bestc < 0 || c < bestc || (c == bestc && nt > best)) { bestc = c; best = nt; }
@@ -345,6 +350,7 @@ void launch(const ConvArgs& a, hipStream_t st) {
 int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
     int nt = pick_nt(a.K);
     int wm = pick_wm(a.M, a.K);
+    if (wm == 4 && nt > 5) nt = 4;
     a.tilesN = cdiv(a.K, 32 * nt);
     if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
     if (wm == 4) {
@@ -353,7 +359,7 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
             case 2: launch<2, 4, 3>(a, st); break;
             case 3: launch<3, 4, 3>(a, st); break;
             case 4: launch<4, 4, 3>(a, st); break;
-            default: launch<5, 4, 3>(a, st); break;
+            default: launch<5, 4, 3>(a, st); break;   // (NT=6 would need 3 x 57 KiB stages)
         }
     } else {
         switch (nt) {
@@ -361,7 +367,8 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
             case 2: launch<2, 2, 2>(a, st); break;
             case 3: launch<3, 2, 2>(a, st); break;
             case 4: launch<4, 2, 2>(a, st); break;
-            default: launch<5, 2, 2>(a, st); break;
+            case 5: launch<5, 2, 2>(a, st); break;
+            default: launch<6, 2, 2>(a, st); break;
         }
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_igemm_bf16");
@@ -391,6 +398,7 @@ extern "C" int ifcbk_conv2d_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const 
     a.ostr_h = d->stride_h; a.ostr_w = d->stride_w; a.base_h = -d->pad_h; a.base_w = -d->pad_w;
     a.ish = 0; a.isw = 0;
     a.M = d->N * d->P * d->Q; a.Kg = d->R * d->S * d->C; a.accumulate = 0; a.PQ = d->P * d->Q;
+    a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
     return run(ctx, a, (hipStream_t)stream);
 }
 
@@ -408,5 +416,6 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     a.base_h = -(d->R - 1 - d->pad_h); a.base_w = -(d->S - 1 - d->pad_w);
     a.ish = d->stride_h == 2 ? 1 : 0; a.isw = d->stride_w == 2 ? 1 : 0;
     a.M = d->N * d->H * d->W; a.Kg = d->R * d->S * d->K; a.accumulate = accumulate; a.PQ = d->H * d->W;
+    a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
     return run(ctx, a, (hipStream_t)stream);
 }

@@ -16,7 +16,7 @@ struct WgradArgs {
     const bf16_t* x;
     const bf16_t* dy;
     float* slab;      // [nsplit][K][RSC]
-    const bf16_t* zero;
+    unsigned xbytes, dybytes;
     int H, W, C, ldx;
     int K, R, S;
     int P, Q, ldy;
@@ -86,6 +86,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
         bcol_s[par] = rs - bcol_r[par] * a.S;
     }
 
+    // buffer_load ... lds through SRDs: an out-of-range offset (padding, tail pixels, tail channels) reads zeros
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int HW = a.H * a.W;
+
 #define ISSUE_TILE(pix0, stage)                                                                                 \
     {                                                                                                           \
         bf16_t* dstA = smem + (stage) * 2 * TILE;                                                               \
@@ -95,18 +101,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
             const int row = (wave * 4 + j) * 4 + lrow4;                                                         \
             const int pix = (pix0) + row;                                                                       \
             const bool pv = pix < pix_end;                                                                      \
-            const bf16_t* srcA = (pv && avalid[par]) ? a.dy + (size_t)pix * a.ldy + k0 + ac16[par] * 8 : a.zero; \
-            __builtin_amdgcn_global_load_lds((gptr_t)srcA, (lptr_t)(dstA + (wave * 4 + j) * 4 * TW), 16, 0, 0);   \
-            bool v = pv && bvalid[par];                                                                         \
-            uint32_t pp = v ? (uint32_t)pix : 0u;                                                               \
+            unsigned voA = (pv && avalid[par]) ? (unsigned)(pix * a.ldy + k0 + ac16[par] * 8) * 2u : OOB;       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 4 * TW), 16, voA, 0, 0, 0); \
+            uint32_t pp = pv ? (uint32_t)pix : 0u;                                                              \
             uint32_t n = fdiv(pp, a.fPQ);                                                                       \
             uint32_t rem = pp - n * a.fPQ.d;                                                                    \
             uint32_t p = fdiv(rem, a.fQ);                                                                       \
             uint32_t q = rem - p * a.fQ.d;                                                                      \
             int hi = (int)p * a.sh - a.ph + bcol_r[par], wi = (int)q * a.sw - a.pw + bcol_s[par];               \
-            v = v && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;                                                \
-            const bf16_t* srcB = v ? a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.ldx + bcol_c[par] : a.zero;  \
-            __builtin_amdgcn_global_load_lds((gptr_t)srcB, (lptr_t)(dstB + (wave * 4 + j) * 4 * TW), 16, 0, 0);   \
+            bool v = pv && bvalid[par] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;         \
+            unsigned voB = v ? (unsigned)(((int)n * HW + hi * a.W + wi) * a.ldx + bcol_c[par]) * 2u : OOB;      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dstB + (wave * 4 + j) * 4 * TW), 16, voB, 0, 0, 0); \
         }                                                                                                       \
     }
 
@@ -249,13 +254,14 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     if (!d || d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad: only bf16 storage is implemented");
     if (d->C % 8 || d->K % 8 || d->ldx % 8 || d->ldy % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: channels must be multiples of 8");
     if (d->Cw > d->C || d->Cw <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: bad Cw");
-    if ((int64_t)d->N * d->P * d->Q >= (1ll << 31) || (int64_t)d->N * d->H * d->W >= (1ll << 31))
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: pixel count exceeds 2^31");
+    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31))
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: a tensor exceeds the 2 GiB buffer-descriptor window");
     Plan p = make_plan(d);
     if (p.ws > ctx->ws_bytes)
         IFCBK_FAIL(ctx, IFCBK_ENOMEM, "wgrad: workspace %zu > reserved %zu (call ifcbk_ctx_reserve)", p.ws, ctx->ws_bytes);
     WgradArgs a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws; a.zero = (const bf16_t*)ctx->zeros;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws;
+    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2); a.dybytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
