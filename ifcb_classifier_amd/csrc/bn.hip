@@ -78,34 +78,48 @@ __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* bet
 }
 
 // ---------------------------------------------------------------- apply
+// per-channel coefficients are staged once per block in LDS (8 chunks per thread amortise it): the payload loads are
+// the only global traffic in the loop
+constexpr int EW_ITER = 8;
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* x, int ldx, const float* scale, const float* shift,
                                                         const bf16_t* res, int ldr, bf16_t* y, int ldy, int64_t M,
-                                                        int cpr) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * cpr) return;
-    int64_t m = i / cpr;
-    int c = (int)(i - m * cpr) * 8;
-    uint4 v = *reinterpret_cast<const uint4*>(x + m * ldx + c);
-    float f[8], sc[8], sh[8];
-    unpack8(v, f);
-    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + c);
-    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
-    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + c);
-    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + c + 4);
-    float r[8];
-    if (RES) {
-        uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
-        unpack8(rv, r);
+                                                        int cpr, fastdiv_t fcpr) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];
+    const int C = cpr * 8;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        coef[c] = scale[c];
+        coef[C + c] = shift[c];
     }
+    __syncthreads();
+    const int64_t total = M * cpr;
+    int64_t i = (int64_t)blockIdx.x * (256 * EW_ITER) + threadIdx.x;
+#pragma unroll 2
+    for (int it = 0; it < EW_ITER; ++it, i += 256) {
+        if (i >= total) break;
+        uint32_t m = fdiv((uint32_t)i, fcpr);
+        int c = ((int)i - (int)m * cpr) * 8;
+        uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + c);
+        float f[8], sc[8], sh[8];
+        unpack8(v, f);
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef + c);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef + c + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef + C + c);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(coef + C + c + 4);
+        float r[8];
+        if (RES) {
+            uint4 rv = *reinterpret_cast<const uint4*>(res + (int64_t)m * ldr + c);
+            unpack8(rv, r);
+        }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float o = f[j] * sc[j] + sh[j];
-        if (RES) o += r[j];
-        if (RELU) o = fmaxf(o, 0.f);
-        f[j] = o;
+        for (int j = 0; j < 8; ++j) {
+            float o = f[j] * sc[j] + sh[j];
+            if (RES) o += r[j];
+            if (RELU) o = fmaxf(o, 0.f);
+            f[j] = o;
+        }
+        *reinterpret_cast<uint4*>(y + (int64_t)m * ldy + c) = pack8(f);
     }
-    *reinterpret_cast<uint4*>(y + m * ldy + c) = pack8(f);
 }
 
 // ---------------------------------------------------------------- backward
@@ -207,44 +221,71 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
     }
 }
 
-// pass 3: dx (and the residual branch gradient)
+// pass 3: dx (and the residual branch gradient).  dx = A_c*dz + B_c*x + K_c with
+//   A = gamma*invstd,  B = -gamma*invstd^2*dgamma/M,  K = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
+// staged per block in LDS together with bn_apply's (scale, shift) for the recomputed ReLU mask.
 template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
                                                          const bf16_t* dy, int lddy, const float* gamma,
                                                          const float* mean, const float* invstd, const float* scale,
                                                          const float* shift, const float* tmp,
                                                          bf16_t* dx, int lddx, bf16_t* dres, int lddres, int dres_acc,
-                                                         int64_t M, int C, float invM) {
-    const int cpr = C / 8;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * cpr) return;
-    int64_t m = i / cpr;
-    int c = (int)(i - m * cpr) * 8;
-    float fx[8], fy[8], fd[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
-    unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
-    if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float dz = fd[j];
-        if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
-        if (MASK == 2) dz = (fx[j] * scale[c + j] + shift[c + j]) > 0.f ? dz : 0.f;
-        fd[j] = dz;
-        float is = invstd[c + j];
-        float xhat = (fx[j] - mean[c + j]) * is;
-        o[j] = gamma[c + j] * is * (dz - tmp[c + j] * invM - xhat * tmp[C + c + j] * invM);
-    }
-    if (dres) {
-        bf16_t* rp = dres + m * lddres + c;
-        if (dres_acc) {
-            float fr[8];
-            unpack8(*reinterpret_cast<const uint4*>(rp), fr);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fd[j] += fr[j];
+                                                         int64_t M, int C, float invM, fastdiv_t fcpr) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float is = invstd[c], a_ = gamma[c] * is, dg = tmp[C + c] * invM, db = tmp[c] * invM;
+        coef[c] = a_;
+        coef[C + c] = -a_ * is * dg;
+        coef[2 * C + c] = a_ * (mean[c] * is * dg - db);
+        if (MASK == 2) {
+            coef[3 * C + c] = scale[c];
+            coef[4 * C + c] = shift[c];
         }
-        *reinterpret_cast<uint4*>(rp) = pack8(fd);
     }
-    *reinterpret_cast<uint4*>(dx + m * lddx + c) = pack8(o);
+    __syncthreads();
+    const int cpr = C / 8;
+    const int64_t total = M * cpr;
+    int64_t i = (int64_t)blockIdx.x * (256 * EW_ITER) + threadIdx.x;
+#pragma unroll 2
+    for (int it = 0; it < EW_ITER; ++it, i += 256) {
+        if (i >= total) break;
+        uint32_t m = fdiv((uint32_t)i, fcpr);
+        int c = ((int)i - (int)m * cpr) * 8;
+        float fx[8], fy[8], fd[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + c), fx);
+        unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)m * lddy + c), fd);
+        if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + (int64_t)m * ldy + c), fy);
+        float ca[8], cb[8], ck[8], sc[8], sh[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(ca + 4 * h) = *reinterpret_cast<const float4*>(coef + c + 4 * h);
+            *reinterpret_cast<float4*>(cb + 4 * h) = *reinterpret_cast<const float4*>(coef + C + c + 4 * h);
+            *reinterpret_cast<float4*>(ck + 4 * h) = *reinterpret_cast<const float4*>(coef + 2 * C + c + 4 * h);
+            if (MASK == 2) {
+                *reinterpret_cast<float4*>(sc + 4 * h) = *reinterpret_cast<const float4*>(coef + 3 * C + c + 4 * h);
+                *reinterpret_cast<float4*>(sh + 4 * h) = *reinterpret_cast<const float4*>(coef + 4 * C + c + 4 * h);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dz = fd[j];
+            if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
+            if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
+            fd[j] = dz;
+            o[j] = ca[j] * dz + (cb[j] * fx[j] + ck[j]);
+        }
+        if (dres) {
+            bf16_t* rp = dres + (int64_t)m * lddres + c;
+            if (dres_acc) {
+                float fr[8];
+                unpack8(*reinterpret_cast<const uint4*>(rp), fr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fd[j] += fr[j];
+            }
+            *reinterpret_cast<uint4*>(rp) = pack8(fd);
+        }
+        *reinterpret_cast<uint4*>(dx + (int64_t)m * lddx + c) = pack8(o);
+    }
 }
 
 }  // namespace
@@ -285,15 +326,18 @@ extern "C" int ifcbk_bn_apply(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void
     if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: bad desc");
     int cpr = d->C / 8;
     int64_t total = (int64_t)d->M * cpr;
-    dim3 grid(cdiv(total, 256)), block(256);
+    dim3 grid(cdiv(total, 256 * EW_ITER)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: tensor too large");
+    const size_t shm = (size_t)2 * d->C * sizeof(float);
+    const fastdiv_t fc = make_fastdiv(cpr);
     const bf16_t* xx = (const bf16_t*)x;
     const bf16_t* rr = (const bf16_t*)residual;
     bf16_t* yy = (bf16_t*)y;
-    if (d->relu && rr) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
-    else if (d->relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
-    else if (rr) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr);
+    if (d->relu && rr) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else if (d->relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else if (rr) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
     IFCBK_LAUNCH_CHECK(ctx, "bn_apply");
     return 0;
 }
@@ -324,9 +368,9 @@ extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* 
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
     int64_t total = M * (C / 8);
     float invM = (float)(1.0 / (double)M);
-    if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
-    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
-    else hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, dim3(cdiv(total, 256)), dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM);
+    if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<2>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
+    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
+    else hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
     return 0;
 }
