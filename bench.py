@@ -169,6 +169,30 @@ def main():
         dt = float(tt.item())
     loss = float(eng.loss.item())
 
+    # secondary number (BASELINE metric is "train + infer"): RUN-mode inference on the same ROIs -- on-GPU
+    # preprocess -> eval forward (BN from running statistics) -> softmax; replicas only, no collective
+    def infer_step():
+        eng.load_rois(**rois)
+        p = eng.forward_eval(B)
+        eng.run(p.softmax)
+
+    for _ in range(2):
+        infer_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ti = time.perf_counter()
+    for _ in range(args.steps):
+        infer_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dti = time.perf_counter() - ti
+    if world > 1:
+        tt = torch.tensor([dti], device=eng.dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dti = float(tt.item())
+
     out = None
     if rank == 0:
         ips = world * B * args.steps / dt
@@ -183,6 +207,9 @@ def main():
             'train_tflops': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3, 2),
             'mfma_frac_whole_step': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
             'final_loss': round(loss, 4),
+            'infer_images_per_s': round(world * B * args.steps / dti, 1),
+            'infer_ms_per_batch': round(1e3 * dti / args.steps, 3),
+            'infer_mfma_frac': round(world * B * args.steps / dti * 11.423e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
         }
         if use_ev:
             n = pl.step.n

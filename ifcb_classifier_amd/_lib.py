@@ -13,12 +13,12 @@ BF16, F32 = 0, 1
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
- OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK) = range(1, 20)
+ OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE) = range(1, 21)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
-            19: 'dropout_mask'}
+            19: 'dropout_mask', 20: 'conv_fwd_affine'}
 
 
 class ConvDesc(C.Structure):
@@ -66,6 +66,7 @@ _PROTOS = {
     'ifcbk_ctx_workspace_bytes': (_sz, [_vp]),
     'ifcbk_last_error': (C.c_char_p, [_vp]),
     'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'ifcbk_conv2d_dgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_wgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_wgrad_workspace': (_sz, [C.POINTER(ConvDesc)]),

@@ -23,6 +23,10 @@ struct ConvArgs {
     const bf16_t* w;
     bf16_t* y;
     float* part;       // [mblocks][2][K] or null
+    const float* ep_scale;   // optional fused epilogue: y = act(acc*scale[n] + shift[n] (+ residual))
+    const float* ep_shift;
+    const bf16_t* ep_res;
+    int ep_ldr, ep_relu;
     unsigned xbytes, wbytes;   // buffer-descriptor extents of x and w
     int H, W, C, ldx;
     int K, R, S;
@@ -261,6 +265,29 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
                     for (int j = 0; j < 8; ++j) fv[j] += fo[j];
                     v = pack8(fv);
                 }
+                if (a.ep_scale) {
+                    float fv[8], sc[8], sh[8];
+                    unpack8(v, fv);
+                    const int nn = n0 + cc * 8;
+                    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(a.ep_scale + nn);
+                    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(a.ep_scale + nn + 4);
+                    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(a.ep_shift + nn);
+                    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(a.ep_shift + nn + 4);
+                    if (a.ep_res) {
+                        float fr[8];
+                        unpack8(*reinterpret_cast<const uint4*>(a.ep_res + (size_t)m * a.ep_ldr + nn), fr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fv[j] = fv[j] * sc[j] + sh[j] + fr[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fv[j] = fv[j] * sc[j] + sh[j];
+                    }
+                    if (a.ep_relu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fv[j] = fmaxf(fv[j], 0.f);
+                    }
+                    v = pack8(fv);
+                }
                 *reinterpret_cast<uint4*>(dst) = v;
                 if (a.part) {
                     float fv[8];
@@ -386,10 +413,26 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     return cdiv(M, 64 * pick_wm(M, d->K));
 }
 
+static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
+                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream);
+
 extern "C" int ifcbk_conv2d_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y,
                                 float* bn_part, void* stream) {
+    return conv_fwd_impl(ctx, d, x, w, y, bn_part, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int ifcbk_conv2d_fwd_affine(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y,
+                                       const float* scale, const float* shift, const void* residual, int ldr, int relu,
+                                       void* stream) {
+    if (!scale || !shift) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine: scale/shift required");
+    return conv_fwd_impl(ctx, d, x, w, y, nullptr, scale, shift, residual, ldr, relu, stream);
+}
+
+static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
+                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
     ConvArgs a;
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = (const bf16_t*)residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part;
     a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
@@ -407,6 +450,7 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     if (int e = check_desc(ctx, d)) return e;
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
+    a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
     a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr;
     a.xbytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
     a.H = d->P; a.W = d->Q; a.C = d->K; a.ldx = d->ldy;

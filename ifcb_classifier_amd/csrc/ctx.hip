@@ -59,6 +59,9 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
     const int acc = o->flags & 1, pacc = (o->flags >> 1) & 1;
     switch (o->kind) {
         case IFCBK_OP_CONV_FWD: return ifcbk_conv2d_fwd(c, &o->u.conv, p[0], p[1], p[2], (float*)p[3], st);
+        case IFCBK_OP_CONV_FWD_AFFINE:
+            return ifcbk_conv2d_fwd_affine(c, &o->u.conv, p[0], p[1], p[2], (const float*)p[3], (const float*)p[4], p[5],
+                                           (int)o->i[0], (o->flags >> 2) & 1, st);
         case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
         case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
         case IFCBK_OP_WEIGHT_PACK: return ifcbk_weight_pack(c, &o->u.conv, (const float*)p[0], p[1], p[2], st);
@@ -160,7 +163,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
     if (!o || !name || cap < 1) return IFCBK_EINVAL;
     name[0] = 0;
     switch (o->kind) {
-        case IFCBK_OP_CONV_FWD: {
+        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
             snprintf(name, cap, "conv_igemm_bf16<%d, %d, %d, false>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
@@ -190,7 +193,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
 extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
     double fl = 0, by = 0;
     switch (o->kind) {
-        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD: {
+        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD: {
             const ifcbk_conv_desc& d = o->u.conv;
             double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
             fl = 2.0 * mac;

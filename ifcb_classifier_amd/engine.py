@@ -139,10 +139,9 @@ class Engine:
         """[TV] initialisation: truncated normal (inception) / kaiming fan_out (resnet); the replaced
         ``fc`` heads use ``nn.Linear``'s default init (neuston_models.py:25-26,39)."""
         g = torch.Generator(device='cpu')
-        if seed is not None:
-            g.manual_seed(int(seed))
-        else:
-            g.seed()
+        if seed is None:        # draw from torch's global RNG so that seed_everything(--seed) makes the init reproducible
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        g.manual_seed(int(seed))
         incep = self.net.name == 'inception_v3'
         for key, (o, n, shape, kind, node) in self.poff.items():
             v = self.pviews[key]
@@ -281,6 +280,12 @@ class Engine:
                 ldr = n.residual.buf.C if n.residual is not None else 0
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
+                        continue
+                    if not train:
+                        # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
+                        lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
+                                p=(self._aptr(n.x), wk, self._aptr(n.y), self._stat(n, 4), self._stat(n, 5), res),
+                                i=(ldr,), flags=4 if n.relu else 0, conv=d)
                         continue
                     lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part) if train else None),
                             conv=dfw)

@@ -64,6 +64,12 @@ typedef struct {
  * ROUNDED outputs, consumed by ifcbk_bn_finalize.                                                    */
 int ifcbk_conv2d_fwd(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y,
                      float* bn_part, void* stream);
+/* inference form: the per-channel affine of an eval-mode BatchNorm (scale/shift from ifcbk_bn_finalize with
+ * part==NULL), the optional resnet residual add and the ReLU are applied in the conv epilogue, so neither the raw
+ * conv output nor a separate bn_apply pass touches HBM:  y = act(conv(x,w)*scale[k] + shift[k] (+ residual)).     */
+int ifcbk_conv2d_fwd_affine(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y,
+                            const float* scale, const float* shift, const void* residual, int ldr, int relu,
+                            void* stream);
 /* dx[n,h,w,c] (+)= sum_{k,r,s} dy[n,p,q,k] * w[k,r,s,c];  wT = bf16 [C][R][S][K] with r,s FLIPPED
  * (made by ifcbk_weight_pack).  accumulate!=0 adds into dx.                                          */
 int ifcbk_conv2d_dgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
@@ -188,7 +194,7 @@ enum {
     IFCBK_OP_BN_FINALIZE, IFCBK_OP_BN_APPLY, IFCBK_OP_BN_BWD,
     IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
-    IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK
+    IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE
 };
 typedef struct {
     int32_t kind;
