@@ -1,5 +1,6 @@
-// BatchNorm (train/eval) fused with ReLU and the resnet residual add; HBM-bound elementwise/reduction
-// kernels: every access is a 16-byte chunk of 8 bf16 channels, consecutive lanes on consecutive chunks.
+// BatchNorm (train/eval) fused with ReLU and the resnet residual add; HBM-bound elementwise/reduction kernels.
+// Every access is a 16-byte chunk (8 bf16 or 4 fp32 channels), consecutive lanes on consecutive chunks; all
+// kernels are templated on the storage type T (bf16 performance mode / fp32 parity mode).
 #include "common.h"
 
 namespace {
@@ -81,12 +82,13 @@ __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* bet
 // per-channel coefficients are staged once per block in LDS (8 chunks per thread amortise it): the payload loads are
 // the only global traffic in the loop
 constexpr int EW_ITER = 8;
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* x, int ldx, const float* scale, const float* shift,
-                                                        const bf16_t* res, int ldr, bf16_t* y, int ldy, int64_t M,
-                                                        int cpr, fastdiv_t fcpr) {
+template <class T, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, int ldx, const float* scale, const float* shift,
+                                                        const T* res, int ldr, T* y, int ldy, int64_t M, int cpr,
+                                                        fastdiv_t fcpr) {
+    constexpr int E = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) float coef[];
-    const int C = cpr * 8;
+    const int C = cpr * E;
     for (int c = threadIdx.x; c < C; c += 256) {
         coef[c] = scale[c];
         coef[C + c] = shift[c];
@@ -98,68 +100,57 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* x, int ldx,
     for (int it = 0; it < EW_ITER; ++it, i += 256) {
         if (i >= total) break;
         uint32_t m = fdiv((uint32_t)i, fcpr);
-        int c = ((int)i - (int)m * cpr) * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + c);
-        float f[8], sc[8], sh[8];
-        unpack8(v, f);
-        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(coef + c);
-        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(coef + c + 4);
-        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(coef + C + c);
-        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(coef + C + c + 4);
-        float r[8];
-        if (RES) {
-            uint4 rv = *reinterpret_cast<const uint4*>(res + (int64_t)m * ldr + c);
-            unpack8(rv, r);
-        }
+        int c = ((int)i - (int)m * cpr) * E;
+        float f[E], r[E];
+        Chunk<T>::load(x + (int64_t)m * ldx + c, f);
+        if (RES) Chunk<T>::load(res + (int64_t)m * ldr + c, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float o = f[j] * sc[j] + sh[j];
+        for (int j = 0; j < E; ++j) {
+            float o = f[j] * coef[c + j] + coef[C + c + j];
             if (RES) o += r[j];
             if (RELU) o = fmaxf(o, 0.f);
             f[j] = o;
         }
-        *reinterpret_cast<uint4*>(y + (int64_t)m * ldy + c) = pack8(f);
+        Chunk<T>::store(y + (int64_t)m * ldy + c, f);
     }
 }
 
 // ---------------------------------------------------------------- backward
-// pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks (64 channels) x 32 rows in flight
+// pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks x 32 rows in flight
 constexpr int BWD_ROWS = 1024;
 // MASK: 0 = no ReLU, 1 = ReLU mask read from y (residual case), 2 = ReLU mask recomputed as x*scale+shift > 0
-// (bit-identical to what bn_apply rounded: same expression, sign survives bf16 rounding) -- saves the y read
-template <int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
-                                                             const bf16_t* dy, int lddy, const float* mean,
-                                                             const float* invstd, const float* scale, const float* shift,
-                                                             float* part, int64_t M, int C) {
-    __shared__ float red[4][2][64];
+// (bit-identical to what bn_apply stored: same expression, the sign survives rounding) -- saves the y read
+template <class T, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
+                                                             const float* mean, const float* invstd, const float* scale,
+                                                             const float* shift, float* part, int64_t M, int C) {
+    constexpr int E = Chunk<T>::N;
+    constexpr int CG = 8 * E;                    // channels per block
+    __shared__ float red[4][2][CG];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cc = t & 7, r0 = t >> 3;
-    const int c = blockIdx.y * 64 + cc * 8;
+    const int c = blockIdx.y * CG + cc * E;
     const int64_t mbeg = (int64_t)blockIdx.x * BWD_ROWS;
     const int64_t mend = mbeg + BWD_ROWS < M ? mbeg + BWD_ROWS : M;
-    float sb[8], sg[8];
+    float sb[E], sg[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sb[j] = sg[j] = 0.f;
+    for (int j = 0; j < E; ++j) sb[j] = sg[j] = 0.f;
     if (c < C) {
-        float mu[8], is[8], sc[8], sh[8];
-        *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(mean + c);
-        *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(mean + c + 4);
-        *reinterpret_cast<float4*>(is) = *reinterpret_cast<const float4*>(invstd + c);
-        *reinterpret_cast<float4*>(is + 4) = *reinterpret_cast<const float4*>(invstd + c + 4);
-        if (MASK == 2) {
-            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + c);
-            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
-            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + c);
-            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + c + 4);
+        float mu[E], is[E], sc[E], sh[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            mu[j] = mean[c + j];
+            is[j] = invstd[c + j];
+            sc[j] = MASK == 2 ? scale[c + j] : 0.f;
+            sh[j] = MASK == 2 ? shift[c + j] : 0.f;
         }
         for (int64_t m = mbeg + r0; m < mend; m += 32) {
-            float fx[8], fy[8], fd[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + m * ldx + c), fx);
-            unpack8(*reinterpret_cast<const uint4*>(dy + m * lddy + c), fd);
-            if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + m * ldy + c), fy);
+            float fx[E], fy[E], fd[E];
+            Chunk<T>::load(x + m * ldx + c, fx);
+            Chunk<T>::load(dy + m * lddy + c, fd);
+            if (MASK == 1) Chunk<T>::load(y + m * ldy + c, fy);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < E; ++j) {
                 float dz = fd[j];
                 if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
                 if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
@@ -171,21 +162,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* x, int
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < E; ++j) {
             sb[j] += __shfl_xor(sb[j], off);
             sg[j] += __shfl_xor(sg[j], off);
         }
     if (lane < 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            red[wave][0][cc * 8 + j] = sb[j];
-            red[wave][1][cc * 8 + j] = sg[j];
+        for (int j = 0; j < E; ++j) {
+            red[wave][0][cc * E + j] = sb[j];
+            red[wave][1][cc * E + j] = sg[j];
         }
     }
     __syncthreads();
-    if (t < 128) {
-        int which = t >> 6, n = t & 63;
-        int ch = blockIdx.y * 64 + n;
+    if (t < 2 * CG) {
+        int which = t / CG, n = t - which * CG;
+        int ch = blockIdx.y * CG + n;
         if (ch < C) {
             float s = red[0][which][n] + red[1][which][n] + red[2][which][n] + red[3][which][n];
             part[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
@@ -224,13 +215,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
 // pass 3: dx (and the residual branch gradient).  dx = A_c*dz + B_c*x + K_c with
 //   A = gamma*invstd,  B = -gamma*invstd^2*dgamma/M,  K = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
 // staged per block in LDS together with bn_apply's (scale, shift) for the recomputed ReLU mask.
-template <int MASK>
-__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx, const bf16_t* y, int ldy,
-                                                         const bf16_t* dy, int lddy, const float* gamma,
-                                                         const float* mean, const float* invstd, const float* scale,
-                                                         const float* shift, const float* tmp,
-                                                         bf16_t* dx, int lddx, bf16_t* dres, int lddres, int dres_acc,
-                                                         int64_t M, int C, float invM, fastdiv_t fcpr) {
+template <class T, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
+                                                         const float* gamma, const float* mean, const float* invstd,
+                                                         const float* scale, const float* shift, const float* tmp,
+                                                         T* dx, int lddx, T* dres, int lddres, int dres_acc, int64_t M,
+                                                         int C, float invM, fastdiv_t fcpr) {
+    constexpr int E = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) float coef[];
     for (int c = threadIdx.x; c < C; c += 256) {
         float is = invstd[c], a_ = gamma[c] * is, dg = tmp[C + c] * invM, db = tmp[c] * invM;
@@ -243,49 +234,97 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const bf16_t* x, int ldx
         }
     }
     __syncthreads();
-    const int cpr = C / 8;
+    const int cpr = C / E;
     const int64_t total = M * cpr;
     int64_t i = (int64_t)blockIdx.x * (256 * EW_ITER) + threadIdx.x;
 #pragma unroll 2
     for (int it = 0; it < EW_ITER; ++it, i += 256) {
         if (i >= total) break;
         uint32_t m = fdiv((uint32_t)i, fcpr);
-        int c = ((int)i - (int)m * cpr) * 8;
-        float fx[8], fy[8], fd[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + c), fx);
-        unpack8(*reinterpret_cast<const uint4*>(dy + (int64_t)m * lddy + c), fd);
-        if (MASK == 1) unpack8(*reinterpret_cast<const uint4*>(y + (int64_t)m * ldy + c), fy);
-        float ca[8], cb[8], ck[8], sc[8], sh[8];
+        int c = ((int)i - (int)m * cpr) * E;
+        float fx[E], fy[E], fd[E], o[E];
+        Chunk<T>::load(x + (int64_t)m * ldx + c, fx);
+        Chunk<T>::load(dy + (int64_t)m * lddy + c, fd);
+        if (MASK == 1) Chunk<T>::load(y + (int64_t)m * ldy + c, fy);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(ca + 4 * h) = *reinterpret_cast<const float4*>(coef + c + 4 * h);
-            *reinterpret_cast<float4*>(cb + 4 * h) = *reinterpret_cast<const float4*>(coef + C + c + 4 * h);
-            *reinterpret_cast<float4*>(ck + 4 * h) = *reinterpret_cast<const float4*>(coef + 2 * C + c + 4 * h);
-            if (MASK == 2) {
-                *reinterpret_cast<float4*>(sc + 4 * h) = *reinterpret_cast<const float4*>(coef + 3 * C + c + 4 * h);
-                *reinterpret_cast<float4*>(sh + 4 * h) = *reinterpret_cast<const float4*>(coef + 4 * C + c + 4 * h);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < E; ++j) {
             float dz = fd[j];
             if (MASK == 1) dz = fy[j] > 0.f ? dz : 0.f;
-            if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
+            if (MASK == 2) dz = (fx[j] * coef[3 * C + c + j] + coef[4 * C + c + j]) > 0.f ? dz : 0.f;
             fd[j] = dz;
-            o[j] = ca[j] * dz + (cb[j] * fx[j] + ck[j]);
+            o[j] = coef[c + j] * dz + (coef[C + c + j] * fx[j] + coef[2 * C + c + j]);
         }
         if (dres) {
-            bf16_t* rp = dres + (int64_t)m * lddres + c;
+            T* rp = dres + (int64_t)m * lddres + c;
             if (dres_acc) {
-                float fr[8];
-                unpack8(*reinterpret_cast<const uint4*>(rp), fr);
+                float fr[E];
+                Chunk<T>::load(rp, fr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) fd[j] += fr[j];
+                for (int j = 0; j < E; ++j) fd[j] += fr[j];
             }
-            *reinterpret_cast<uint4*>(rp) = pack8(fd);
+            Chunk<T>::store(rp, fd);
         }
-        *reinterpret_cast<uint4*>(dx + (int64_t)m * lddx + c) = pack8(o);
+        Chunk<T>::store(dx + (int64_t)m * lddx + c, o);
     }
+}
+
+template <class T>
+int apply_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const float* scale, const float* shift,
+            const void* residual, int ldr, void* y, hipStream_t st) {
+    constexpr int E = Chunk<T>::N;
+    if (d->C % E || d->ldx % E || d->ldy % E) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: channels must be multiples of %d", E);
+    const int cpr = d->C / E;
+    const int64_t total = (int64_t)d->M * cpr;
+    if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: tensor too large");
+    dim3 grid(cdiv(total, 256 * EW_ITER)), block(256);
+    const size_t shm = (size_t)2 * d->C * sizeof(float);
+    const fastdiv_t fc = make_fastdiv(cpr);
+    const T* xx = (const T*)x; const T* rr = (const T*)residual; T* yy = (T*)y;
+    if (d->relu && rr) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else if (d->relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else if (rr) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_apply");
+    return 0;
+}
+
+template <class T>
+int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy, int lddy,
+          const float* gamma, const float* mean, const float* invstd, void* dx, int lddx, void* dres, int lddres,
+          int dres_accumulate, float* dgamma, float* dbeta, int param_accumulate, const float* scale, const float* shift,
+          hipStream_t st) {
+    constexpr int E = Chunk<T>::N;
+    constexpr int CG = 8 * E;
+    const int C = d->C;
+    if (C % E || d->ldx % E || lddy % E || lddx % E) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: channels must be multiples of %d", E);
+    const int64_t M = d->M;
+    int ntiles = cdiv(M, BWD_ROWS);
+    size_t need = ((size_t)ntiles * 2 * C + 2 * C) * sizeof(float);
+    if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd: workspace %zu > reserved %zu", need, ctx->ws_bytes);
+    float* part = (float*)ctx->ws;
+    float* tmp = part + (size_t)ntiles * 2 * C;
+    const T* xx = (const T*)x; const T* yy = (const T*)y; const T* dd = (const T*)dy;
+    dim3 g1(ntiles, cdiv(C, CG));
+    // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
+    const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
+    if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
+    const int64_t total = M * (C / E);
+    if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: tensor too large");
+    const float invM = (float)(1.0 / (double)M);
+    dim3 g3(cdiv(total, 256 * EW_ITER));
+    const size_t shm = (size_t)5 * C * sizeof(float);
+    const fastdiv_t fc = make_fastdiv(C / E);
+    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 2>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
+    else hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 0>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
+    return 0;
 }
 
 }  // namespace
@@ -323,54 +362,22 @@ extern "C" int ifcbk_bn_finalize(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const f
 
 extern "C" int ifcbk_bn_apply(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const float* scale,
                               const float* shift, const void* residual, int ldr, void* y, void* stream) {
-    if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: bad desc");
-    int cpr = d->C / 8;
-    int64_t total = (int64_t)d->M * cpr;
-    dim3 grid(cdiv(total, 256 * EW_ITER)), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: tensor too large");
-    const size_t shm = (size_t)2 * d->C * sizeof(float);
-    const fastdiv_t fc = make_fastdiv(cpr);
-    const bf16_t* xx = (const bf16_t*)x;
-    const bf16_t* rr = (const bf16_t*)residual;
-    bf16_t* yy = (bf16_t*)y;
-    if (d->relu && rr) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
-    else if (d->relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
-    else if (rr) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, shm, st, xx, d->ldx, scale, shift, rr, ldr, yy, d->ldy, (int64_t)d->M, cpr, fc);
-    IFCBK_LAUNCH_CHECK(ctx, "bn_apply");
-    return 0;
+    if (!d) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: null desc");
+    if (d->dtype == IFCBK_F32) return apply_t<float>(ctx, d, x, scale, shift, residual, ldr, y, (hipStream_t)stream);
+    if (d->dtype == IFCBK_BF16) return apply_t<bf16_t>(ctx, d, x, scale, shift, residual, ldr, y, (hipStream_t)stream);
+    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_apply: bad dtype");
 }
 
 extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy,
                             int lddy, const float* gamma, const float* mean, const float* invstd, void* dx, int lddx,
                             void* dres, int lddres, int dres_accumulate, float* dgamma, float* dbeta,
                             int param_accumulate, const float* scale, const float* shift, void* stream) {
-    if (!d || d->dtype != IFCBK_BF16 || d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: bad desc");
-    const int C = d->C;
-    const int64_t M = d->M;
-    int ntiles = cdiv(M, BWD_ROWS);
-    size_t need = ((size_t)ntiles * 2 * C + 2 * C) * sizeof(float);
-    if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd: workspace %zu > reserved %zu", need, ctx->ws_bytes);
-    float* part = (float*)ctx->ws;
-    float* tmp = part + (size_t)ntiles * 2 * C;
-    hipStream_t st = (hipStream_t)stream;
-    const bf16_t* xx = (const bf16_t*)x; const bf16_t* yy = (const bf16_t*)y; const bf16_t* dd = (const bf16_t*)dy;
-    dim3 g1(ntiles, cdiv(C, 64));
-    // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
-    const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
-    if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
-    if (mask == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
-    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
-    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
-    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
-    int64_t total = M * (C / 8);
-    float invM = (float)(1.0 / (double)M);
-    if (mask == 2) hipLaunchKernelGGL(bn_bwd_dx_kernel<2>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
-    else if (mask == 1) hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
-    else hipLaunchKernelGGL(bn_bwd_dx_kernel<0>, dim3(cdiv(total, 256 * EW_ITER)), dim3(256), (size_t)5 * C * sizeof(float), st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, dres_accumulate, M, C, invM, make_fastdiv(C / 8));
-    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
-    return 0;
+    if (!d) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: null desc");
+    if (d->dtype == IFCBK_F32)
+        return bwd_t<float>(ctx, d, x, y, dy, lddy, gamma, mean, invstd, dx, lddx, dres, lddres, dres_accumulate, dgamma,
+                            dbeta, param_accumulate, scale, shift, (hipStream_t)stream);
+    if (d->dtype == IFCBK_BF16)
+        return bwd_t<bf16_t>(ctx, d, x, y, dy, lddy, gamma, mean, invstd, dx, lddx, dres, lddres, dres_accumulate, dgamma,
+                             dbeta, param_accumulate, scale, shift, (hipStream_t)stream);
+    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: bad dtype");
 }

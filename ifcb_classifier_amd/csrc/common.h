@@ -63,6 +63,26 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// ---- storage-type generic 16-byte chunk (8 bf16 or 4 fp32 channels): every HBM access of the elementwise kernels
+template <class T> struct Chunk;
+template <> struct Chunk<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
+    __device__ static __forceinline__ void store(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
+};
+template <> struct Chunk<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float* f) { *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void store(float* p, const float* f) { *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f); }
+};
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+template <class T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+static inline int dtype_esize(int dtype) { return dtype == IFCBK_F32 ? 4 : 2; }
+static inline int dtype_chunk(int dtype) { return dtype == IFCBK_F32 ? 4 : 8; }
+
 // exact unsigned division by a runtime constant for n < 2^31 (host builds, device applies)
 struct fastdiv_t {
     uint32_t mul, shift, d;

@@ -19,13 +19,13 @@
 namespace {
 
 struct ConvArgs {
-    const bf16_t* x;
-    const bf16_t* w;
-    bf16_t* y;
+    const void* x;
+    const void* w;
+    void* y;
     float* part;       // [mblocks][2][K] or null
     const float* ep_scale;   // optional fused epilogue: y = act(acc*scale[n] + shift[n] (+ residual))
     const float* ep_shift;
-    const bf16_t* ep_res;
+    const void* ep_res;
     int ep_ldr, ep_relu;
     unsigned xbytes, wbytes;   // buffer-descriptor extents of x and w
     int H, W, C, ldx;
@@ -39,18 +39,36 @@ struct ConvArgs {
     fastdiv_t fPQ, fQ;
 };
 
-constexpr int BK = 64;
-
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// LDS image of a tile: [rows][8 chunks of 16 B]; chunk c of row r lives at physical chunk c ^ (r & 7), which
-// makes every ds_read_b128 fragment read conflict-free.  The image is filled by LDS-DMA
-// (global_load_lds_dwordx4: destination = wave-uniform base + lane*16), so the swizzle is applied on the
+// LDS image of a tile: [rows][8 chunks of 16 B] (128-byte rows: 64 bf16 or 32 fp32 of k); chunk c of row r lives at
+// physical chunk c ^ (r & 7), which makes every ds_read_b128 fragment read conflict-free.  The image is filled by
+// LDS-DMA (buffer_load_dwordx4 ... lds: destination = wave-uniform base + lane*16), so the swizzle is applied on the
 // SOURCE side: the lane that lands on (row, phys) fetches logical chunk phys ^ (row & 7).
-__device__ __forceinline__ const bf16x8_t* frag_ptr(const bf16_t* tile, int row, int chunk) {
-    return reinterpret_cast<const bf16x8_t*>(tile + row * BK + ((chunk ^ (row & 7)) << 3));
-}
+template <class T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8_t frag_t;                        // 8 consecutive k of one row
+    __device__ static __forceinline__ void run(const frag_t& a, const frag_t& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void pack4(bf16_t* p, const f32x4_t& v) {
+        uint2 u;
+        u.x = pack2bf(v[0], v[1]);
+        u.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+// fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  A lane's 16-byte fragment holds 4 k values; the
+// four MFMAs of a fragment pair use element j of both operands, i.e. a permuted but CONSISTENT k order.
+template <> struct Mma<float> {
+    typedef f32x4_t frag_t;
+    __device__ static __forceinline__ void run(const frag_t& a, const frag_t& b, f32x4_t& c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void pack4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -59,8 +77,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NT: 16-column tiles per wave in N (block N = 32*NT); WM: waves along M (block M = 64*WM, threads = 128*WM);
 // NSTAGE: LDS ring depth (NSTAGE-1 tiles of LDS-DMA in flight across the per-step barrier, counted vmcnt).
-template <int NT, int WM, int NSTAGE, bool STRIDED>
-__global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
+template <class T, int NT, int WM, int NSTAGE, bool STRIDED>
+__global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CE = 16 / ES;                        // elements per 16-byte chunk
+    constexpr int BK = 128 / ES;                       // k elements per tile step (128-byte rows)
+    typedef typename Mma<T>::frag_t frag_t;
     constexpr int NW = 2 * WM;
     constexpr int NTHREADS = 64 * NW;
     constexpr int BM = 64 * WM;
@@ -68,19 +90,19 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
     constexpr int JB = (NT * 4 + NW - 1) / NW;         // B-tile LDS-DMA instructions per wave per tile
     constexpr int G = 4 + JB;                          // LDS-DMA instructions per wave per tile
     constexpr int D = NSTAGE - 1;                      // prefetch distance (tiles)
-    constexpr int CPR = BN / 8;                        // 16-byte chunks per output row
+    constexpr int CPR = BN / CE;                       // 16-byte chunks per output row
     constexpr int CPRP = CPR <= 4 ? 4 : CPR <= 8 ? 8 : CPR <= 16 ? 16 : 32;
-    constexpr int LDC = BN + 8;                        // C-tile row stride (elements)
+    constexpr int LDC = BN + CE;                       // C-tile row stride (elements)
     constexpr int STAGE = (BM + BN) * BK;              // elements per pipeline stage
-    constexpr int STAGE_BYTES = NSTAGE * STAGE * 2;
-    constexpr int CT_BYTES = BM * LDC * 2 + NW * BN * 2 * 4;
+    constexpr int STAGE_BYTES = NSTAGE * STAGE * ES;
+    constexpr int CT_BYTES = BM * LDC * ES + NW * BN * 2 * 4;
     constexpr int MAIN_BYTES = STAGE_BYTES > CT_BYTES ? STAGE_BYTES : CT_BYTES;
     constexpr int DUMMY_BYTES = (JB * NW > NT * 4) ? 1024 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + DUMMY_BYTES];
-    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem);             // [NSTAGE][A: BM*BK | B: BN*BK]
-    bf16_t* sC = reinterpret_cast<bf16_t*>(smem);                 // [BM][LDC] (epilogue)
-    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * 2);  // [NW][2][BN] (epilogue)
-    bf16_t* sDummy = reinterpret_cast<bf16_t*>(smem + MAIN_BYTES); // sink of the padding LDS-DMA (uniform vmcnt)
+    T* sStage = reinterpret_cast<T*>(smem);                       // [NSTAGE][A: BM*BK | B: BN*BK]
+    T* sC = reinterpret_cast<T*>(smem);                           // [BM][LDC] (epilogue)
+    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * ES); // [NW][2][BN] (epilogue)
+    T* sDummy = reinterpret_cast<T*>(smem + MAIN_BYTES);          // sink of the padding LDS-DMA (uniform vmcnt)
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -115,8 +137,8 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
     }
     int kc, kr, ks, tapoff;
     {
-        // csrc*8 < 64: a short subtract loop instead of two integer divisions
-        kc = csrc * 8;
+        // csrc*CE < BK: a short subtract loop instead of two integer divisions
+        kc = csrc * CE;
         kr = 0;
         ks = 0;
         while (kc >= a.C) {
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
         int grp = j * NW + wave;
         gvalid[j] = grp < NT * 4;
         int n = n0 + grp * 8 + lrow8;
-        woff[j] = (gvalid[j] && n < a.K) ? (unsigned)(n * a.Kg + csrc * 8) * 2u : OOB;
+        woff[j] = (gvalid[j] && n < a.K) ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
     }
     const int nk = (a.Kg + BK - 1) / BK;
     const int hmask = (1 << a.ish) - 1, wmask = (1 << a.isw) - 1;
@@ -140,8 +162,8 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
 
 #define ISSUE_TILE(kt, stage)                                                                              \
     {                                                                                                      \
-        bf16_t* dstA = sStage + (stage) * STAGE;                                                           \
-        bf16_t* dstB = dstA + BM * BK;                                                                     \
+        T* dstA = sStage + (stage) * STAGE;                                                                \
+        T* dstB = dstA + BM * BK;                                                                     \
         const bool kvalid = kr < a.R;                                                                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
             int hr = bh[j] + kr, wr = bw[j] + ks;                                                          \
@@ -150,18 +172,18 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
                 bool v = kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0);       \
                 int hi = hr >> a.ish, wi = wr >> a.isw;                                                    \
                 v = v && hi < a.H && wi < a.W;                                                             \
-                voff = v ? (unsigned)(off0[j] + (hi * a.W + wi) * a.ldx + kc) * 2u : OOB;                  \
+                voff = v ? (unsigned)(off0[j] + (hi * a.W + wi) * a.ldx + kc) * (unsigned)ES : OOB;                  \
             } else {                                                                                       \
                 bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;           \
-                voff = v ? (unsigned)(off0[j] + tapoff) * 2u : OOB;                                        \
+                voff = v ? (unsigned)(off0[j] + tapoff) * (unsigned)ES : OOB;                                     \
             }                                                                                              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, voff, 0, 0, 0); \
         }                                                                                                  \
-        const bool kv2 = ((kt) * BK + csrc * 8) < a.Kg;                                                    \
+        const bool kv2 = ((kt) * BK + csrc * CE) < a.Kg;                                                    \
         _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                                   \
-            unsigned voff = kv2 ? woff[j] + (unsigned)(kt) * (BK * 2) : OOB;                               \
+            unsigned voff = kv2 ? woff[j] + (unsigned)(kt) * 128u : OOB;                                    \
             voff = woff[j] == OOB ? OOB : voff;                                                            \
-            bf16_t* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                            \
+            T* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff, 0, 0, 0);                 \
         }                                                                                                  \
         kc += BK;                                                                                          \
@@ -186,11 +208,11 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
 
     const int frow = lane & 15, fchunk = lane >> 4;
     // fragment addresses: the swizzle term depends only on (frow & 7, fchunk, kk); m/n tiles are immediates
-    const bf16_t* fA[2];
-    const bf16_t* fB[2];
+    const T* fA[2];
+    const T* fB[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) << 3;
+        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) * CE;
         fA[kk] = sStage + (wm * 64 + frow) * BK + ph;
         fB[kk] = sStage + BM * BK + (wn * (NT * 16) + frow) * BK + ph;
     }
@@ -207,18 +229,18 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
         const int soff = stage * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[4], fb[NT];
-            const bf16_t* pa = fA[kk] + soff;
-            const bf16_t* pb = fB[kk] + soff;
+            frag_t fa[4], fb[NT];
+            const T* pa = fA[kk] + soff;
+            const T* pb = fB[kk] + soff;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(pa + mt * 16 * BK);
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const frag_t*>(pa + mt * 16 * BK);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const bf16x8_t*>(pb + nt * 16 * BK);
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const frag_t*>(pb + nt * 16 * BK);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+                    Mma<T>::run(fb[nt], fa[mt], acc[nt][mt]);
         }
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
         istage = istage + 1 == NSTAGE ? 0 : istage + 1;
@@ -235,10 +257,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
             for (int mt = 0; mt < 4; ++mt) {
                 int m = wm * 64 + mt * 16 + frow;
                 int n = wn * (NT * 16) + nt * 16 + 4 * g;
-                uint2 v;
-                v.x = pack2bf(acc[nt][mt][0], acc[nt][mt][1]);
-                v.y = pack2bf(acc[nt][mt][2], acc[nt][mt][3]);
-                *reinterpret_cast<uint2*>(sC + m * LDC + n) = v;
+                Mma<T>::pack4(sC + m * LDC + n, acc[nt][mt]);
             }
     }
     __syncthreads();
@@ -246,73 +265,70 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
         constexpr int RPP = NTHREADS / CPRP;
         const int cc = t & (CPRP - 1);
         const int r0 = t / CPRP;
-        const bool cvalid = (cc < CPR) && (n0 + cc * 8 < a.K);
-        float s1[8], s2[8];
+        const bool cvalid = (cc < CPR) && (n0 + cc * CE < a.K);
+        float s1[CE], s2[CE];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+        for (int j = 0; j < CE; ++j) s1[j] = s2[j] = 0.f;
         if (cvalid) {
+            const int nn = n0 + cc * CE;
+            float sc[CE], sh[CE];
+            if (a.ep_scale) {
+#pragma unroll
+                for (int j = 0; j < CE; ++j) {
+                    sc[j] = a.ep_scale[nn + j];
+                    sh[j] = a.ep_shift[nn + j];
+                }
+            }
             for (int r = r0; r < BM; r += RPP) {
                 int m = m0 + r;
                 if (m >= a.M) break;
-                uint4 v = *reinterpret_cast<const uint4*>(sC + r * LDC + cc * 8);
-                bf16_t* dst = a.y + (size_t)m * a.ldy + n0 + cc * 8;
-                if (a.accumulate) {
-                    uint4 o = *reinterpret_cast<const uint4*>(dst);
-                    float fo[8], fv[8];
-                    unpack8(o, fo);
-                    unpack8(v, fv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) fv[j] += fo[j];
-                    v = pack8(fv);
-                }
-                if (a.ep_scale) {
-                    float fv[8], sc[8], sh[8];
-                    unpack8(v, fv);
-                    const int nn = n0 + cc * 8;
-                    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(a.ep_scale + nn);
-                    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(a.ep_scale + nn + 4);
-                    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(a.ep_shift + nn);
-                    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(a.ep_shift + nn + 4);
-                    if (a.ep_res) {
-                        float fr[8];
-                        unpack8(*reinterpret_cast<const uint4*>(a.ep_res + (size_t)m * a.ep_ldr + nn), fr);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) fv[j] = fv[j] * sc[j] + sh[j] + fr[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) fv[j] = fv[j] * sc[j] + sh[j];
-                    }
-                    if (a.ep_relu) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) fv[j] = fmaxf(fv[j], 0.f);
-                    }
-                    v = pack8(fv);
-                }
-                *reinterpret_cast<uint4*>(dst) = v;
+                float fv[CE];
+                Chunk<T>::load(sC + r * LDC + cc * CE, fv);          // values as they are stored (rounded for bf16)
+                T* dst = (T*)a.y + (size_t)m * a.ldy + nn;
                 if (a.part) {
-                    float fv[8];
-                    unpack8(v, fv);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < CE; ++j) {
                         s1[j] += fv[j];
                         s2[j] += fv[j] * fv[j];
                     }
                 }
+                if (a.accumulate) {
+                    float fo[CE];
+                    Chunk<T>::load(dst, fo);
+#pragma unroll
+                    for (int j = 0; j < CE; ++j) fv[j] += fo[j];
+                }
+                if (a.ep_scale) {
+                    if (a.ep_res) {
+                        float fr[CE];
+                        Chunk<T>::load((const T*)a.ep_res + (size_t)m * a.ep_ldr + nn, fr);
+#pragma unroll
+                        for (int j = 0; j < CE; ++j) fv[j] = fv[j] * sc[j] + sh[j] + fr[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CE; ++j) fv[j] = fv[j] * sc[j] + sh[j];
+                    }
+                    if (a.ep_relu) {
+#pragma unroll
+                        for (int j = 0; j < CE; ++j) fv[j] = fmaxf(fv[j], 0.f);
+                    }
+                }
+                Chunk<T>::store(dst, fv);
             }
         }
         if (a.part) {
 #pragma unroll
             for (int off = CPRP; off < 64; off <<= 1)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < CE; ++j) {
                     s1[j] += __shfl_xor(s1[j], off);
                     s2[j] += __shfl_xor(s2[j], off);
                 }
             if (lane < CPRP && cc < CPR) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sRed[(wave * 2 + 0) * BN + cc * 8 + j] = s1[j];
-                    sRed[(wave * 2 + 1) * BN + cc * 8 + j] = s2[j];
+                for (int j = 0; j < CE; ++j) {
+                    sRed[(wave * 2 + 0) * BN + cc * CE + j] = s1[j];
+                    sRed[(wave * 2 + 1) * BN + cc * CE + j] = s2[j];
                 }
             }
             __syncthreads();
@@ -329,10 +345,10 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_bf16(ConvArgs a) {
     }
 }
 
-int pick_nt(int K) {
+int pick_nt(int K, int maxnt = 6) {
     int best = 1;
     long bestc = -1;
-    for (int nt = 1; nt <= 6; ++nt) {
+    for (int nt = 1; nt <= maxnt; ++nt) {
         int bn = 32 * nt;
         long c = (long)cdiv(K, bn) * (bn + 48);
         if (bestc < 0 || c < bestc || (c == bestc && nt > best)) { bestc = c; best = nt; }
@@ -342,69 +358,74 @@ int pick_nt(int K) {
 
 int check_desc(ifcbk_ctx* ctx, const ifcbk_conv_desc* d) {
     if (!d) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: null desc");
-    if (d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv: only bf16 storage is implemented");
-    if (d->C % 8 || d->K % 8 || d->ldx % 8 || d->ldy % 8 || d->C <= 0 || d->K <= 0)
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: C=%d K=%d ldx=%d ldy=%d must be positive multiples of 8", d->C, d->K, d->ldx, d->ldy);
+    if (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv: dtype must be bf16 or f32");
+    const int ce = dtype_chunk(d->dtype), es = dtype_esize(d->dtype);
+    if (d->C % ce || d->K % ce || d->ldx % ce || d->ldy % ce || d->C <= 0 || d->K <= 0)
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: C=%d K=%d ldx=%d ldy=%d must be positive multiples of %d", d->C, d->K, d->ldx, d->ldy, ce);
     if (d->stride_h < 1 || d->stride_h > 2 || d->stride_w < 1 || d->stride_w > 2)
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: stride must be 1 or 2");
     int P = (d->H + 2 * d->pad_h - d->R) / d->stride_h + 1, Q = (d->W + 2 * d->pad_w - d->S) / d->stride_w + 1;
     if (P != d->P || Q != d->Q) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: P,Q=%d,%d inconsistent (expect %d,%d)", d->P, d->Q, P, Q);
-    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31))
+    if ((int64_t)d->N * d->P * d->Q * d->ldy * es >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * es >= (1ll << 31))
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: a tensor exceeds the 2 GiB buffer-descriptor window");
     return 0;
 }
 
-// block-M choice: 256-pixel tiles (8 waves, 3-stage ring, 1 block/CU) when they still fill the chip several times
-// over; otherwise 128-pixel tiles (4 waves, 2-stage ring, 2 blocks/CU) for the small-M layers
+// block-M choice: 128-pixel tiles (4 waves, 2-stage ring, 2 blocks/CU) beat 256-pixel tiles (8 waves, 3-stage ring,
+// 1 block/CU) on every inception layer measured in round 1; IFCBK_CONV_WM=4 forces the large tile for experiments
 int pick_wm(int M, int K) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("IFCBK_CONV_WM"); force = e ? atoi(e) : 0; }
-    if (force == 2 || force == 4) return force;
-    int nt = pick_nt(K);
-    long tiles256 = (long)cdiv(M, 256) * cdiv(K, 32 * nt);
-    (void)tiles256;
-    return 2;   // measured: 128-pixel tiles with 2 blocks/CU beat 256-pixel tiles on every inception layer (r1)
+    (void)M; (void)K;
+    return force == 4 ? 4 : 2;
 }
 
-template <int NT, int WM, int NSTAGE>
+template <class T, int NT, int WM, int NSTAGE>
 void launch(const ConvArgs& a, hipStream_t st) {
     int tilesM = cdiv(a.M, 64 * WM);
     dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
-    if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm_bf16<NT, WM, NSTAGE, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16<NT, WM, NSTAGE, false>), grid, block, 0, st, a);
+    if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, false>), grid, block, 0, st, a);
 }
 
-int run(ifcbk_ctx* ctx, ConvArgs& a, hipStream_t st) {
-    int nt = pick_nt(a.K);
-    int wm = pick_wm(a.M, a.K);
-    if (wm == 4 && nt > 5) nt = 4;
+int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
+    const bool f32 = dtype == IFCBK_F32;
+    int wm = f32 ? 2 : pick_wm(a.M, a.K);
+    int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6));
     a.tilesN = cdiv(a.K, 32 * nt);
     if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
-    if (wm == 4) {
+    if (f32) {
         switch (nt) {
-            case 1: launch<1, 4, 3>(a, st); break;
-            case 2: launch<2, 4, 3>(a, st); break;
-            case 3: launch<3, 4, 3>(a, st); break;
-            case 4: launch<4, 4, 3>(a, st); break;
-            default: launch<5, 4, 3>(a, st); break;   // (NT=6 would need 3 x 57 KiB stages)
+            case 1: launch<float, 1, 2, 2>(a, st); break;
+            case 2: launch<float, 2, 2, 2>(a, st); break;
+            case 3: launch<float, 3, 2, 2>(a, st); break;
+            default: launch<float, 4, 2, 2>(a, st); break;
+        }
+    } else if (wm == 4) {
+        switch (nt) {
+            case 1: launch<bf16_t, 1, 4, 3>(a, st); break;
+            case 2: launch<bf16_t, 2, 4, 3>(a, st); break;
+            case 3: launch<bf16_t, 3, 4, 3>(a, st); break;
+            case 4: launch<bf16_t, 4, 4, 3>(a, st); break;
+            default: launch<bf16_t, 5, 4, 3>(a, st); break;
         }
     } else {
         switch (nt) {
-            case 1: launch<1, 2, 2>(a, st); break;
-            case 2: launch<2, 2, 2>(a, st); break;
-            case 3: launch<3, 2, 2>(a, st); break;
-            case 4: launch<4, 2, 2>(a, st); break;
-            case 5: launch<5, 2, 2>(a, st); break;
-            default: launch<6, 2, 2>(a, st); break;
+            case 1: launch<bf16_t, 1, 2, 2>(a, st); break;
+            case 2: launch<bf16_t, 2, 2, 2>(a, st); break;
+            case 3: launch<bf16_t, 3, 2, 2>(a, st); break;
+            case 4: launch<bf16_t, 4, 2, 2>(a, st); break;
+            case 5: launch<bf16_t, 5, 2, 2>(a, st); break;
+            default: launch<bf16_t, 6, 2, 2>(a, st); break;
         }
     }
-    IFCBK_LAUNCH_CHECK(ctx, "conv_igemm_bf16");
+    IFCBK_LAUNCH_CHECK(ctx, "conv_igemm");
     return 0;
 }
 
 }  // namespace
 
-int ifcbk_conv_fwd_nt(int K) { return pick_nt(K); }
+int ifcbk_conv_fwd_nt(int K) { return pick_nt(K, pick_wm(0, K) == 4 ? 5 : 6); }
 
 int ifcbk_conv_fwd_wm(int M, int K) { return pick_wm(M, K); }
 
@@ -432,9 +453,10 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
     ConvArgs a;
-    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = (const bf16_t*)residual; a.ep_ldr = ldr; a.ep_relu = relu;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.part = bn_part;
-    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
+    a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
+    a.x = x; a.w = w; a.y = y; a.part = bn_part;
+    const int es = dtype_esize(d->dtype);
+    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * es);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S;
     a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
@@ -442,7 +464,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     a.ish = 0; a.isw = 0;
     a.M = d->N * d->P * d->Q; a.Kg = d->R * d->S * d->C; a.accumulate = 0; a.PQ = d->P * d->Q;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
-    return run(ctx, a, (hipStream_t)stream);
+    return run(ctx, a, d->dtype, (hipStream_t)stream);
 }
 
 extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
@@ -451,8 +473,9 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
-    a.x = (const bf16_t*)dy; a.w = (const bf16_t*)wT; a.y = (bf16_t*)dx; a.part = nullptr;
-    a.xbytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * 2);
+    a.x = dy; a.w = wT; a.y = dx; a.part = nullptr;
+    const int es = dtype_esize(d->dtype);
+    a.xbytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * es); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * es);
     a.H = d->P; a.W = d->Q; a.C = d->K; a.ldx = d->ldy;
     a.K = d->C; a.R = d->R; a.S = d->S;
     a.P = d->H; a.Q = d->W; a.ldy = d->ldx;
@@ -461,5 +484,5 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     a.ish = d->stride_h == 2 ? 1 : 0; a.isw = d->stride_w == 2 ? 1 : 0;
     a.M = d->N * d->H * d->W; a.Kg = d->R * d->S * d->K; a.accumulate = accumulate; a.PQ = d->H * d->W;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
-    return run(ctx, a, (hipStream_t)stream);
+    return run(ctx, a, d->dtype, (hipStream_t)stream);
 }

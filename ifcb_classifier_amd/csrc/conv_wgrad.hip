@@ -13,8 +13,8 @@
 namespace {
 
 struct WgradArgs {
-    const bf16_t* x;
-    const bf16_t* dy;
+    const void* x;
+    const void* dy;
     float* slab;      // [nsplit][K][RSC]
     unsigned xbytes, dybytes;
     int H, W, C, ldx;
@@ -173,6 +173,112 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
         }
 }
 
+// ---------------------------------------------------------------- fp32 parity-mode wgrad
+// Same decomposition on v_mfma_f32_16x16x4_f32.  Tiles are [32 pixels][128 fp32 columns] (512-byte rows, one wave
+// LDS-DMA instruction fills two rows); a lane's MFMA operand is ONE float -- A[k = lane>>4][m = lane&15] -- so the
+// pixel-major image is read directly with ds_read_b32, no transpose needed.
+constexpr int F_BKP = 32;
+constexpr int F_TILE = F_BKP * TW;      // floats
+
+template <int MT>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_f32(WgradArgs a) {
+    constexpr int BMW = 32 * MT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * F_TILE];     // [stage][A | B]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / a.tiles;
+    const int tile = lin - split * a.tiles;
+    const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
+    const int k0 = mtile * BMW, n0 = ntile * BNW;
+    const int pix_begin = split * a.split_len;
+    const int pix_end = min(pix_begin + a.split_len, a.M);
+    const int lrow2 = lane >> 5, c32 = lane & 31;
+    const bool avalid = (c32 * 4 < BMW) && (k0 + c32 * 4 < a.K);
+    int br, bs, bc;
+    bool bvalid;
+    {
+        int jcol = n0 + c32 * 4;
+        bvalid = jcol < a.RSC;
+        int jj = bvalid ? jcol : 0;
+        int rs = jj / a.C;
+        bc = jj - rs * a.C;
+        br = rs / a.S;
+        bs = rs - br * a.S;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int HW = a.H * a.W;
+
+#define ISSUE_F32(pix0, stage)                                                                                  \
+    {                                                                                                           \
+        float* dstA = smem + (stage) * 2 * F_TILE;                                                              \
+        float* dstB = dstA + F_TILE;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const int row = (wave * 4 + j) * 2 + lrow2;                                                         \
+            const int pix = (pix0) + row;                                                                       \
+            const bool pv = pix < pix_end;                                                                      \
+            unsigned voA = (pv && avalid) ? (unsigned)(pix * a.ldy + k0 + c32 * 4) * 4u : OOB;                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 2 * TW), 16, voA, 0, 0, 0); \
+            uint32_t pp = pv ? (uint32_t)pix : 0u;                                                              \
+            uint32_t n = fdiv(pp, a.fPQ);                                                                       \
+            uint32_t rem = pp - n * a.fPQ.d;                                                                    \
+            uint32_t p = fdiv(rem, a.fQ);                                                                       \
+            uint32_t q = rem - p * a.fQ.d;                                                                      \
+            int hi = (int)p * a.sh - a.ph + br, wi = (int)q * a.sw - a.pw + bs;                                 \
+            bool v = pv && bvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;              \
+            unsigned voB = v ? (unsigned)(((int)n * HW + hi * a.W + wi) * a.ldx + bc) * 4u : OOB;               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dstB + (wave * 4 + j) * 2 * TW), 16, voB, 0, 0, 0); \
+        }                                                                                                       \
+    }
+
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (pix_end - pix_begin + F_BKP - 1) / F_BKP;
+    if (nsteps > 0) ISSUE_F32(pix_begin, 0)
+    __syncthreads();
+    const int g = lane >> 4, li = lane & 15;
+    for (int st = 0; st < nsteps; ++st) {
+        const int stage = st & 1;
+        if (st + 1 < nsteps) ISSUE_F32(pix_begin + (st + 1) * F_BKP, stage ^ 1)
+        const float* tA = smem + stage * 2 * F_TILE;
+        const float* tB = tA + F_TILE;
+#pragma unroll
+        for (int k4 = 0; k4 < F_BKP / 4; ++k4) {
+            const int krow = k4 * 4 + g;
+            float fa[MT], fb[4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = tA[krow * TW + wm * (MT * 16) + mt * 16 + li];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fb[nt] = tB[krow * TW + wn * 64 + nt * 16 + li];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef ISSUE_F32
+    float* out = a.slab + (size_t)split * a.K * a.RSC;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            int col = n0 + wn * 64 + nt * 16 + li;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = k0 + wm * (MT * 16) + mt * 16 + 4 * g + j;
+                if (k < a.K && col < a.RSC) out[(size_t)k * a.RSC + col] = acc[mt][nt][j];
+            }
+        }
+}
+
 // dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]; 64 outputs x 4 split lanes per block, the 4 lane sums are
 // combined in a fixed order (bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw,
@@ -219,18 +325,19 @@ struct Plan { int mt, tilesM, tilesN, nsplit, split_len; size_t ws; };
 
 Plan make_plan(const ifcbk_conv_desc* d) {
     Plan p;
+    const int bkp = d->dtype == IFCBK_F32 ? F_BKP : BKP;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     int RSC = d->R * d->S * d->C;
     p.mt = pick_mt(d->K);
     p.tilesM = cdiv(d->K, 32 * p.mt);
     p.tilesN = cdiv(RSC, BNW);
     int tiles = p.tilesM * p.tilesN;
-    int64_t steps = (M + BKP - 1) / BKP;
+    int64_t steps = (M + bkp - 1) / bkp;
     int64_t ns = cdiv(1024, tiles);
     int64_t maxsplit = steps / 8 > 0 ? steps / 8 : 1;
     if (ns > maxsplit) ns = maxsplit;
     if (ns < 1) ns = 1;
-    int64_t len = ((steps + ns - 1) / ns) * BKP;
+    int64_t len = ((steps + ns - 1) / ns) * bkp;
     ns = (M + len - 1) / len;
     p.nsplit = (int)ns;
     p.split_len = (int)len;
@@ -251,17 +358,18 @@ extern "C" size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc* d) { retur
 
 extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* dw,
                                   int accumulate, void* stream) {
-    if (!d || d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad: only bf16 storage is implemented");
-    if (d->C % 8 || d->K % 8 || d->ldx % 8 || d->ldy % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: channels must be multiples of 8");
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad: dtype must be bf16 or f32");
+    const int ce = dtype_chunk(d->dtype), es = dtype_esize(d->dtype);
+    if (d->C % ce || d->K % ce || d->ldx % ce || d->ldy % ce) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: channels must be multiples of %d", ce);
     if (d->Cw > d->C || d->Cw <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: bad Cw");
-    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31))
+    if ((int64_t)d->N * d->P * d->Q * d->ldy * es >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * es >= (1ll << 31))
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: a tensor exceeds the 2 GiB buffer-descriptor window");
     Plan p = make_plan(d);
     if (p.ws > ctx->ws_bytes)
         IFCBK_FAIL(ctx, IFCBK_ENOMEM, "wgrad: workspace %zu > reserved %zu (call ifcbk_ctx_reserve)", p.ws, ctx->ws_bytes);
     WgradArgs a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ctx->ws;
-    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2); a.dybytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2);
+    a.x = x; a.dy = dy; a.slab = (float*)ctx->ws;
+    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es); a.dybytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * es);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
     a.K = d->K; a.R = d->R; a.S = d->S; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
@@ -269,11 +377,21 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     a.split_len = p.split_len; a.tilesN = p.tilesN; a.tiles = p.tilesM * p.tilesN;
     a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
     hipStream_t st = (hipStream_t)stream;
-    switch (p.mt) {
-        case 1: launch<1>(a, p, st); break;
-        case 2: launch<2>(a, p, st); break;
-        case 3: launch<3>(a, p, st); break;
-        default: launch<4>(a, p, st); break;
+    if (d->dtype == IFCBK_F32) {
+        dim3 grid(p.tilesM * p.tilesN * p.nsplit), block(NTHREADS);
+        switch (p.mt) {
+            case 1: hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL(conv_wgrad_f32<2>, grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL(conv_wgrad_f32<3>, grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL(conv_wgrad_f32<4>, grid, block, 0, st, a); break;
+        }
+    } else {
+        switch (p.mt) {
+            case 1: launch<1>(a, p, st); break;
+            case 2: launch<2>(a, p, st); break;
+            case 3: launch<3>(a, p, st); break;
+            default: launch<4>(a, p, st); break;
+        }
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
     int64_t total = (int64_t)d->K * d->R * d->S * d->Cw;
@@ -285,8 +403,9 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
 
 // ---------------------------------------------------------------- weight pack
 namespace {
-// w[k][rs][c] (bf16, c<C zero padded) and wT[c][RS-1-rs][k]
-__global__ void weight_pack_kernel(const float* wm, bf16_t* w, bf16_t* wT, int K, int RS, int C, int Cw) {
+// w[k][rs][c] (storage type T, c<C zero padded) and wT[c][RS-1-rs][k]
+template <class T>
+__global__ void weight_pack_kernel(const float* wm, T* w, T* wT, int K, int RS, int C, int Cw) {
     int64_t total = (int64_t)K * RS * C;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -295,7 +414,7 @@ __global__ void weight_pack_kernel(const float* wm, bf16_t* w, bf16_t* wT, int K
     int rs = (int)(krs % RS);
     int k = (int)(krs / RS);
     float v = c < Cw ? wm[krs * Cw + c] : 0.f;
-    bf16_t b = f2bf(v);
+    T b = from_f32<T>(v);
     w[i] = b;
     if (wT) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = b;
 }
@@ -303,10 +422,14 @@ __global__ void weight_pack_kernel(const float* wm, bf16_t* w, bf16_t* wT, int K
 
 extern "C" int ifcbk_weight_pack(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const float* w_master, void* w, void* wT,
                                  void* stream) {
-    if (!d || d->dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "weight_pack: only bf16");
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "weight_pack: bad dtype");
     int64_t total = (int64_t)d->K * d->R * d->S * d->C;
-    hipLaunchKernelGGL(weight_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_master,
-                       (bf16_t*)w, (bf16_t*)wT, d->K, d->R * d->S, d->C, d->Cw);
+    if (d->dtype == IFCBK_F32)
+        hipLaunchKernelGGL(weight_pack_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_master,
+                           (float*)w, (float*)wT, d->K, d->R * d->S, d->C, d->Cw);
+    else
+        hipLaunchKernelGGL(weight_pack_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_master,
+                           (bf16_t*)w, (bf16_t*)wT, d->K, d->R * d->S, d->C, d->Cw);
     IFCBK_LAUNCH_CHECK(ctx, "weight_pack");
     return 0;
 }

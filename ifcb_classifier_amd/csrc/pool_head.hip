@@ -15,24 +15,51 @@ PoolArgs make_pool(const ifcbk_pool_desc* d, bool bwd) {
     PoolArgs a;
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx; a.R = d->R; a.S = d->S;
     a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
-    a.cpr = d->C / 8;
+    a.cpr = d->C / dtype_chunk(d->dtype);
     a.total = (int64_t)d->N * (bwd ? (int64_t)d->H * d->W : (int64_t)d->P * d->Q) * a.cpr;
     return a;
 }
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* x, bf16_t* y, uint8_t* arg, PoolArgs a) {
+template <int E> struct ArgPack;
+template <> struct ArgPack<8> {
+    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
+        uint2 v;
+        v.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        v.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bi[j] = ((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xff;
+    }
+};
+template <> struct ArgPack<4> {
+    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
+        *reinterpret_cast<uint32_t*>(p) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
+        uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bi[j] = (v >> (8 * j)) & 0xff;
+    }
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, uint8_t* arg, PoolArgs a) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
-    int c = (int)(i % a.cpr) * 8;
+    int c = (int)(i % a.cpr) * E;
     int64_t pix = i / a.cpr;
     int q = (int)(pix % a.Q);
     int64_t t2 = pix / a.Q;
     int p = (int)(t2 % a.P);
     int64_t n = t2 / a.P;
-    float best[8];
-    int bi[8];
+    float best[E];
+    int bi[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int j = 0; j < E; ++j) { best[j] = -INFINITY; bi[j] = 0; }
     bool first = true;
     for (int r = 0; r < a.R; ++r) {
         int h = p * a.sh - a.ph + r;
@@ -40,36 +67,32 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* x, bf16_
         for (int s = 0; s < a.S; ++s) {
             int w = q * a.sw - a.pw + s;
             if (w < 0 || w >= a.W) continue;
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + ((n * a.H + h) * a.W + w) * a.ldx + c), f);
+            float f[E];
+            Chunk<T>::load(x + ((n * a.H + h) * a.W + w) * a.ldx + c, f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < E; ++j)
                 if (first || f[j] > best[j] || f[j] != f[j]) { best[j] = f[j]; bi[j] = r * a.S + s; }
             first = false;
         }
     }
-    *reinterpret_cast<uint4*>(y + pix * a.ldy + c) = pack8(best);
-    if (arg) {
-        uint2 v;
-        v.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-        v.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
-        *reinterpret_cast<uint2*>(arg + pix * a.C + c) = v;
-    }
+    Chunk<T>::store(y + pix * a.ldy + c, best);
+    if (arg) ArgPack<E>::store(arg + pix * a.C + c, bi);
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* dy, const uint8_t* arg, bf16_t* dx, PoolArgs a,
-                                                           int accumulate) {
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dy, const uint8_t* arg, T* dx, PoolArgs a, int accumulate) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
-    int c = (int)(i % a.cpr) * 8;
+    int c = (int)(i % a.cpr) * E;
     int64_t pix = i / a.cpr;
     int w = (int)(pix % a.W);
     int64_t t2 = pix / a.W;
     int h = (int)(t2 % a.H);
     int64_t n = t2 / a.H;
-    float g[8];
+    float g[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    for (int j = 0; j < E; ++j) g[j] = 0.f;
     int plo = h + a.ph - a.R + 1; plo = plo <= 0 ? 0 : (plo + a.sh - 1) / a.sh;
     int phi = (h + a.ph) / a.sh; if (phi >= a.P) phi = a.P - 1;
     int qlo = w + a.pw - a.S + 1; qlo = qlo <= 0 ? 0 : (qlo + a.sw - 1) / a.sw;
@@ -78,119 +101,125 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* dy, cons
         for (int q = qlo; q <= qhi; ++q) {
             int want = (h - (p * a.sh - a.ph)) * a.S + (w - (q * a.sw - a.pw));
             int64_t opix = (n * a.P + p) * a.Q + q;
-            uint2 av = *reinterpret_cast<const uint2*>(arg + opix * a.C + c);
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(dy + opix * a.ldy + c), f);
+            int idx[E];
+            ArgPack<E>::load(arg + opix * a.C + c, idx);
+            float f[E];
+            Chunk<T>::load(dy + opix * a.ldy + c, f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int idx = ((j < 4 ? av.x : av.y) >> (8 * (j & 3))) & 0xff;
-                if (idx == want) g[j] += f[j];
-            }
+            for (int j = 0; j < E; ++j)
+                if (idx[j] == want) g[j] += f[j];
         }
-    bf16_t* dp = dx + pix * a.ldx + c;
+    T* dp = dx + pix * a.ldx + c;
     if (accumulate) {
-        float o[8];
-        unpack8(*reinterpret_cast<const uint4*>(dp), o);
+        float o[E];
+        Chunk<T>::load(dp, o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] += o[j];
+        for (int j = 0; j < E; ++j) g[j] += o[j];
     }
-    *reinterpret_cast<uint4*>(dp) = pack8(g);
+    Chunk<T>::store(dp, g);
 }
 
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* x, bf16_t* y, PoolArgs a) {
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, T* y, PoolArgs a) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
-    int c = (int)(i % a.cpr) * 8;
+    int c = (int)(i % a.cpr) * E;
     int64_t pix = i / a.cpr;
     int q = (int)(pix % a.Q);
     int64_t t2 = pix / a.Q;
     int p = (int)(t2 % a.P);
     int64_t n = t2 / a.P;
-    float acc[8];
+    float acc[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < E; ++j) acc[j] = 0.f;
     for (int r = 0; r < a.R; ++r) {
         int h = p * a.sh - a.ph + r;
         if (h < 0 || h >= a.H) continue;
         for (int s = 0; s < a.S; ++s) {
             int w = q * a.sw - a.pw + s;
             if (w < 0 || w >= a.W) continue;
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + ((n * a.H + h) * a.W + w) * a.ldx + c), f);
+            float f[E];
+            Chunk<T>::load(x + ((n * a.H + h) * a.W + w) * a.ldx + c, f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            for (int j = 0; j < E; ++j) acc[j] += f[j];
         }
     }
     const float inv = 1.f / (float)(a.R * a.S);     // count_include_pad=True
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] *= inv;
-    *reinterpret_cast<uint4*>(y + pix * a.ldy + c) = pack8(acc);
+    for (int j = 0; j < E; ++j) acc[j] *= inv;
+    Chunk<T>::store(y + pix * a.ldy + c, acc);
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* dy, bf16_t* dx, PoolArgs a, int accumulate) {
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* dy, T* dx, PoolArgs a, int accumulate) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
-    int c = (int)(i % a.cpr) * 8;
+    int c = (int)(i % a.cpr) * E;
     int64_t pix = i / a.cpr;
     int w = (int)(pix % a.W);
     int64_t t2 = pix / a.W;
     int h = (int)(t2 % a.H);
     int64_t n = t2 / a.H;
-    float g[8];
+    float g[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    for (int j = 0; j < E; ++j) g[j] = 0.f;
     int plo = h + a.ph - a.R + 1; plo = plo <= 0 ? 0 : (plo + a.sh - 1) / a.sh;
     int phi = (h + a.ph) / a.sh; if (phi >= a.P) phi = a.P - 1;
     int qlo = w + a.pw - a.S + 1; qlo = qlo <= 0 ? 0 : (qlo + a.sw - 1) / a.sw;
     int qhi = (w + a.pw) / a.sw; if (qhi >= a.Q) qhi = a.Q - 1;
     for (int p = plo; p <= phi; ++p)
         for (int q = qlo; q <= qhi; ++q) {
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4*>(dy + ((n * a.P + p) * a.Q + q) * a.ldy + c), f);
+            float f[E];
+            Chunk<T>::load(dy + ((n * a.P + p) * a.Q + q) * a.ldy + c, f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] += f[j];
+            for (int j = 0; j < E; ++j) g[j] += f[j];
         }
     const float inv = 1.f / (float)(a.R * a.S);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] *= inv;
-    bf16_t* dp = dx + pix * a.ldx + c;
+    for (int j = 0; j < E; ++j) g[j] *= inv;
+    T* dp = dx + pix * a.ldx + c;
     if (accumulate) {
-        float o[8];
-        unpack8(*reinterpret_cast<const uint4*>(dp), o);
+        float o[E];
+        Chunk<T>::load(dp, o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] += o[j];
+        for (int j = 0; j < E; ++j) g[j] += o[j];
     }
-    *reinterpret_cast<uint4*>(dp) = pack8(g);
+    Chunk<T>::store(dp, g);
 }
 
 int pool_check(ifcbk_ctx* ctx, const ifcbk_pool_desc* d) {
-    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || d->ldx % 8 || d->ldy % 8)
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: bad desc (bf16, channels %%8)");
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: bad desc");
+    const int e = dtype_chunk(d->dtype);
+    if (d->C % e || d->ldx % e || d->ldy % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: channels must be multiples of %d", e);
     if (d->R * d->S > 255) IFCBK_FAIL(ctx, IFCBK_EINVAL, "pool: window too large");
     return 0;
 }
 
 // ---------------------------------------------------------------- head
 // feat[n][c] = mean_hw x[n,hw,c] * (mask ? mask*keep_scale : 1)
-__global__ __launch_bounds__(256) void gap_kernel(const bf16_t* x, int ldx, int HW, int C, int64_t total, const uint8_t* mask,
+template <class T>
+__global__ __launch_bounds__(256) void gap_kernel(const T* x, int ldx, int HW, int C, int64_t total, const uint8_t* mask,
                                                   float keep_scale, float* feat) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    int cpr = C / 8;
-    int c = (int)(i % cpr) * 8;
+    int cpr = C / E;
+    int c = (int)(i % cpr) * E;
     int64_t n = i / cpr;
-    float acc[8];
+    float acc[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < E; ++j) acc[j] = 0.f;
     for (int hw = 0; hw < HW; ++hw) {
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (n * HW + hw) * ldx + c), f);
+        float f[E];
+        Chunk<T>::load(x + (n * HW + hw) * ldx + c, f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        for (int j = 0; j < E; ++j) acc[j] += f[j];
     }
     const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E; ++j) {
         float v = acc[j] * inv;
         if (mask) v *= mask[n * C + c + j] ? keep_scale : 0.f;
         feat[n * C + c + j] = v;
@@ -231,33 +260,33 @@ __global__ void fc_bgrad_kernel(const float* dl, float* db, int N, int NC, int a
     for (int n = 0; n < N; ++n) s += dl[(size_t)n * NC + j];
     db[j] = accumulate ? db[j] + s : s;
 }
-// dx[n,hw,c] = (sum_j dl[n][j] W[j][c]) * mask*scale / HW ; thread per (n, chunk of 8 channels)
+// dx[n,hw,c] = (sum_j dl[n][j] W[j][c]) * mask*scale / HW ; thread per (n, 16-byte chunk of channels)
+template <class T>
 __global__ __launch_bounds__(256) void head_dx_kernel(const float* dl, const float* W, const uint8_t* mask, float keep_scale,
-                                                      bf16_t* dx, int lddx, int HW, int C, int NC, int64_t total) {
+                                                      T* dx, int lddx, int HW, int C, int NC, int64_t total) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    int cpr = C / 8;
-    int c = (int)(i % cpr) * 8;
+    int cpr = C / E;
+    int c = (int)(i % cpr) * E;
     int64_t n = i / cpr;
-    float g[8];
+    float g[E];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    for (int j = 0; j < E; ++j) g[j] = 0.f;
     for (int k = 0; k < NC; ++k) {
         float d = dl[n * NC + k];
         const float* w = W + (size_t)k * C + c;
-        float4 w0 = *reinterpret_cast<const float4*>(w), w1 = *reinterpret_cast<const float4*>(w + 4);
-        g[0] += d * w0.x; g[1] += d * w0.y; g[2] += d * w0.z; g[3] += d * w0.w;
-        g[4] += d * w1.x; g[5] += d * w1.y; g[6] += d * w1.z; g[7] += d * w1.w;
+#pragma unroll
+        for (int j = 0; j < E; ++j) g[j] += d * w[j];
     }
     const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E; ++j) {
         float v = g[j] * inv;
         if (mask) v *= mask[n * C + c + j] ? keep_scale : 0.f;
         g[j] = v;
     }
-    uint4 pk = pack8(g);
-    for (int hw = 0; hw < HW; ++hw) *reinterpret_cast<uint4*>(dx + (n * HW + hw) * lddx + c) = pk;
+    for (int hw = 0; hw < HW; ++hw) Chunk<T>::store(dx + (n * HW + hw) * lddx + c, g);
 }
 
 // counter-based Bernoulli mask (splitmix64 of seed, offset+i)
@@ -359,35 +388,37 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
 }
 
 // ---------------------------------------------------------------- layout
+template <class T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, int C, int64_t HW, int64_t total, int Cpad,
                                                            float s0, float s1, float s2, float t0, float t1, float t2,
-                                                           bf16_t* y) {
+                                                           T* y) {
+    constexpr int E = Chunk<T>::N;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index n*HW + hw
     if (i >= total) return;
     int64_t n = i / HW, hw = i - n * HW;
     const float* src = x + n * C * HW + hw;
     float sc[3] = {s0, s1, s2}, sh[3] = {t0, t1, t2};
-    for (int c0 = 0; c0 < Cpad; c0 += 8) {
-        float f[8];
+    for (int c0 = 0; c0 < Cpad; c0 += E) {
+        float f[E];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < E; ++j) {
             int c = c0 + j;
             float v = c < C ? src[c * HW] : 0.f;
             if (c < 3 && c < C) v = v * sc[c] + sh[c];
             f[j] = v;
         }
-        *reinterpret_cast<uint4*>(y + i * Cpad + c0) = pack8(f);
+        Chunk<T>::store(y + i * Cpad + c0, f);
     }
 }
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int C, int64_t HW, int64_t total, int ldx,
-                                                           float* y) {
+template <class T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* x, int C, int64_t HW, int64_t total, int ldx, float* y) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n*C*HW, hw fastest
     if (i >= total) return;
     int64_t hw = i % HW;
     int64_t nc = i / HW;
     int c = (int)(nc % C);
     int64_t n = nc / C;
-    y[i] = bf2f(x[(n * HW + hw) * ldx + c]);
+    y[i] = to_f32(x[(n * HW + hw) * ldx + c]);
 }
 
 }  // namespace
@@ -397,7 +428,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int 
 extern "C" int ifcbk_maxpool_fwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, void* y, uint8_t* argmax, void* stream) {
     if (int e = pool_check(ctx, d)) return e;
     PoolArgs a = make_pool(d, false);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, argmax, a);
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const float*)x, (float*)y, argmax, a);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, argmax, a);
     IFCBK_LAUNCH_CHECK(ctx, "maxpool_fwd");
     return 0;
 }
@@ -405,31 +437,37 @@ extern "C" int ifcbk_maxpool_bwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const
                                  int accumulate, void* stream) {
     if (int e = pool_check(ctx, d)) return e;
     PoolArgs a = make_pool(d, true);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, argmax, (bf16_t*)dx, a, accumulate);
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const float*)dy, argmax, (float*)dx, a, accumulate);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, argmax, (bf16_t*)dx, a, accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "maxpool_bwd");
     return 0;
 }
 extern "C" int ifcbk_avgpool_fwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, void* y, void* stream) {
     if (int e = pool_check(ctx, d)) return e;
     PoolArgs a = make_pool(d, false);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, a);
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const float*)x, (float*)y, a);
+    else hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, a);
     IFCBK_LAUNCH_CHECK(ctx, "avgpool_fwd");
     return 0;
 }
 extern "C" int ifcbk_avgpool_bwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* dy, void* dx, int accumulate, void* stream) {
     if (int e = pool_check(ctx, d)) return e;
     PoolArgs a = make_pool(d, true);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, a, accumulate);
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const float*)dy, (float*)dx, a, accumulate);
+    else hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)dy, (bf16_t*)dx, a, accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "avgpool_bwd");
     return 0;
 }
 
 extern "C" int ifcbk_head_fwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const void* x, const uint8_t* mask, const float* W,
                               const float* b, float* feat, float* logits, void* stream) {
-    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || d->ldx % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: bad desc");
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: bad desc");
+    const int e = dtype_chunk(d->dtype);
+    if (d->C % e || d->ldx % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: channels must be multiples of %d", e);
     if ((size_t)d->C * 4 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
-    int64_t total = (int64_t)d->N * (d->C / 8);
-    hipLaunchKernelGGL(gap_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
+    int64_t total = (int64_t)d->N * (d->C / e);
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(gap_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const float*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
+    else hipLaunchKernelGGL(gap_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
     IFCBK_LAUNCH_CHECK(ctx, "gap");
     hipLaunchKernelGGL(fc_fwd_kernel, dim3(d->N), dim3(256), d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->C, d->NC);
     IFCBK_LAUNCH_CHECK(ctx, "fc_fwd");
@@ -438,14 +476,17 @@ extern "C" int ifcbk_head_fwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const vo
 extern "C" int ifcbk_head_bwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const float* dlogits, const float* feat,
                               const uint8_t* mask, const float* W, float* dW, float* db, void* dx, int lddx,
                               int param_accumulate, void* stream) {
-    if (!d || d->dtype != IFCBK_BF16 || d->C % 8 || lddx % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: bad desc");
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: bad desc");
+    const int e = dtype_chunk(d->dtype);
+    if (d->C % e || lddx % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: channels must be multiples of %d", e);
     hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((int64_t)d->NC * d->C, 256)), dim3(256), 0, ST, dlogits, feat, dW, d->N, d->C, d->NC, param_accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "fc_wgrad");
     hipLaunchKernelGGL(fc_bgrad_kernel, dim3(cdiv(d->NC, 64)), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "fc_bgrad");
     if (dx) {
-        int64_t total = (int64_t)d->N * (d->C / 8);
-        hipLaunchKernelGGL(head_dx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, dlogits, W, mask, d->keep_scale, (bf16_t*)dx, lddx, d->HW, d->C, d->NC, total);
+        int64_t total = (int64_t)d->N * (d->C / e);
+        if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(head_dx_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, dlogits, W, mask, d->keep_scale, (float*)dx, lddx, d->HW, d->C, d->NC, total);
+        else hipLaunchKernelGGL(head_dx_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, ST, dlogits, W, mask, d->keep_scale, (bf16_t*)dx, lddx, d->HW, d->C, d->NC, total);
         IFCBK_LAUNCH_CHECK(ctx, "head_dx");
     }
     return 0;
@@ -488,20 +529,22 @@ extern "C" int ifcbk_sgd_flat(ifcbk_ctx* ctx, float* p, const float* g, float* m
 
 extern "C" int ifcbk_nchw_to_nhwc(ifcbk_ctx* ctx, const float* x, int N, int C, int H, int W, int Cpad, int dtype,
                                   const float* scale3, const float* shift3, void* y, void* stream) {
-    if (dtype != IFCBK_BF16 || Cpad % 8 || C > Cpad) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nchw_to_nhwc: bad args");
+    if ((dtype != IFCBK_BF16 && dtype != IFCBK_F32) || Cpad % dtype_chunk(dtype) || C > Cpad) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nchw_to_nhwc: bad args");
     int64_t total = (int64_t)N * H * W;
     float s[3] = {1, 1, 1}, t[3] = {0, 0, 0};
     if (scale3) for (int i = 0; i < 3; ++i) s[i] = scale3[i];
     if (shift3) for (int i = 0; i < 3; ++i) t[i] = shift3[i];
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, x, C, (int64_t)H * W, total, Cpad, s[0], s[1], s[2], t[0], t[1], t[2], (bf16_t*)y);
+    if (dtype == IFCBK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, x, C, (int64_t)H * W, total, Cpad, s[0], s[1], s[2], t[0], t[1], t[2], (float*)y);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, ST, x, C, (int64_t)H * W, total, Cpad, s[0], s[1], s[2], t[0], t[1], t[2], (bf16_t*)y);
     IFCBK_LAUNCH_CHECK(ctx, "nchw_to_nhwc");
     return 0;
 }
 extern "C" int ifcbk_nhwc_to_nchw_f32(ifcbk_ctx* ctx, const void* x, int N, int C, int H, int W, int ldx, int dtype, float* y,
                                       void* stream) {
-    if (dtype != IFCBK_BF16) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nhwc_to_nchw: bad args");
+    if (dtype != IFCBK_BF16 && dtype != IFCBK_F32) IFCBK_FAIL(ctx, IFCBK_EINVAL, "nhwc_to_nchw: bad args");
     int64_t total = (int64_t)N * C * H * W;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, C, (int64_t)H * W, total, ldx, y);
+    if (dtype == IFCBK_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const float*)x, C, (int64_t)H * W, total, ldx, y);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, C, (int64_t)H * W, total, ldx, y);
     IFCBK_LAUNCH_CHECK(ctx, "nhwc_to_nchw");
     return 0;
 }

@@ -67,7 +67,8 @@ struct RoiArgs {
     const int32_t* ws;
     const uint8_t* flips;
     const int32_t* tab;
-    bf16_t* out;
+    void* out;
+    int f32;
     uint8_t* out_u8;
     int n_img, S, cin, cout, kmax;
     float mean[3], std[3], tsc[3], tsh[3];
@@ -120,7 +121,13 @@ __global__ __launch_bounds__(256) void roi_resize_kernel(RoiArgs a) {
                 }
                 f[j] = v;
             }
-            *reinterpret_cast<uint4*>(a.out + i * a.cout + c0) = pack8(f);
+            if (a.f32) {
+                float* o = (float*)a.out + i * a.cout + c0;
+                *reinterpret_cast<float4*>(o) = make_float4(f[0], f[1], f[2], f[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            } else {
+                *reinterpret_cast<uint4*>((bf16_t*)a.out + i * a.cout + c0) = pack8(f);
+            }
         }
     }
 }
@@ -143,7 +150,7 @@ extern "C" int ifcbk_roi_preprocess(ifcbk_ctx* ctx, const ifcbk_roi_desc* d, con
                                     const int32_t* hs, const int32_t* ws, const uint8_t* flips, int max_h, int max_w,
                                     void* out, uint8_t* out_u8, void* stream) {
     if (!d || d->n_img <= 0) return IFCBK_OK;   // empty bin: nothing to do
-    if (d->dtype != IFCBK_BF16 || (d->in_channels != 1 && d->in_channels != 3) || d->out_channels % 8 || d->out_channels < 8)
+    if ((d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32) || (d->in_channels != 1 && d->in_channels != 3) || d->out_channels % 8 || d->out_channels < 8)
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "roi_preprocess: bad desc");
     if (max_h < 1 || max_w < 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "roi_preprocess: max dims");
     size_t need = ifcbk_roi_preprocess_workspace(d, max_h, max_w);
@@ -155,7 +162,7 @@ extern "C" int ifcbk_roi_preprocess(ifcbk_ctx* ctx, const ifcbk_roi_desc* d, con
     IFCBK_LAUNCH_CHECK(ctx, "roi_coeffs");
     RoiArgs a;
     a.pixels = pixels; a.offs = offs; a.hs = hs; a.ws = ws; a.flips = d->flip_bits_valid ? flips : nullptr;
-    a.tab = (const int32_t*)ctx->ws; a.out = (bf16_t*)out; a.out_u8 = out_u8;
+    a.tab = (const int32_t*)ctx->ws; a.out = out; a.f32 = d->dtype == IFCBK_F32; a.out_u8 = out_u8;
     a.n_img = d->n_img; a.S = d->S; a.cin = d->in_channels; a.cout = d->out_channels; a.kmax = kmax;
     for (int i = 0; i < 3; ++i) { a.mean[i] = d->mean[i]; a.std[i] = d->std[i]; a.tsc[i] = d->tin_scale[i]; a.tsh[i] = d->tin_shift[i]; }
     int64_t total = (int64_t)d->n_img * d->S * d->S;

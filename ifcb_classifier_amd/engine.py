@@ -66,10 +66,16 @@ class Program:
 class Engine:
     """Device state of one model replica."""
 
-    def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16'):
         if not torch.cuda.is_available():
             raise RuntimeError('ifcb_classifier_amd needs a HIP device (MI355X); none is visible and there is no CPU path')
         self.net = net
+        if dtype not in ('bf16', 'fp32'):
+            raise ValueError("dtype must be 'bf16' (performance) or 'fp32' (parity mode)")
+        self.dtype = dtype
+        self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self.esize = 2 if dtype == 'bf16' else 4
+        self.cdtype = _lib.BF16 if dtype == 'bf16' else _lib.F32
         self.dev = torch.device('cuda', device)
         torch.cuda.set_device(self.dev)
         self.ctx = _lib.Context(device)
@@ -132,7 +138,7 @@ class Engine:
             soff += n.K * n.R * n.S * n.x.C
             n.st_off = stoff
             stoff += 6 * n.K          # mean, invstd, scale, shift, eval_scale, eval_shift
-        self.Wsh = torch.zeros(soff, dtype=torch.bfloat16, device=dev)
+        self.Wsh = torch.zeros(soff, dtype=self.tdtype, device=dev)
         self.stats = torch.zeros(stoff, dtype=torch.float32, device=dev)
 
     def init_weights(self, seed=None):
@@ -174,7 +180,7 @@ class Engine:
     # ------------------------------------------------------------------ activations
     def _alloc_acts(self):
         net, dev, N = self.net, self.dev, self.max_batch
-        bf = torch.bfloat16
+        bf = self.tdtype
         self.act = {}
         self.grad = {}
         for b in net.bufs:
@@ -223,17 +229,16 @@ class Engine:
     def activation_bytes(self):
         tot = sum(t.numel() * t.element_size() for t in self.act.values())
         tot += sum(t.numel() * t.element_size() for t in self.grad.values())
-        return tot + self.draw.numel() * 2
+        return tot + self.draw.numel() * self.esize
 
     # ------------------------------------------------------------------ descriptors
-    @staticmethod
-    def _conv_desc(n, N):
+    def _conv_desc(self, n, N):
         return ConvDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.K, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q,
-                        n.y.buf.C, n.Cw, _lib.BF16)
+                        n.y.buf.C, n.Cw, self.cdtype)
 
     def _aptr(self, view, grad=False):
         t = (self.grad if grad else self.act)[view.buf.id]
-        return _vp(t, 2 * view.coff)
+        return _vp(t, self.esize * view.coff)
 
     def _pptr(self, key, which='P'):
         o = self.poff[key][0]
@@ -271,11 +276,11 @@ class Engine:
                 dfw = ConvDesc.from_buffer_copy(d)
                 dfw.ldy = n.K
                 raw = _vp(self.act[n.raw.id])
-                wk = _vp(self.Wsh, 2 * n.w_off)
-                wT = _vp(self.Wsh, 2 * n.wT_off)
+                wk = _vp(self.Wsh, self.esize * n.w_off)
+                wT = _vp(self.Wsh, self.esize * n.wT_off)
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 mb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
-                bnd = BnDesc(M, n.K, n.K, n.y.buf.C, 1 if n.relu else 0, _lib.BF16, n.eps, 0.1)
+                bnd = BnDesc(M, n.K, n.K, n.y.buf.C, 1 if n.relu else 0, self.cdtype, n.eps, 0.1)
                 res = self._aptr(n.residual) if n.residual is not None else None
                 ldr = n.residual.buf.C if n.residual is not None else 0
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
@@ -311,7 +316,7 @@ class Engine:
                 bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad))
             elif n.kind in ('max', 'avg'):
                 pd = PoolDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q, n.y.buf.C,
-                              _lib.BF16)
+                              self.cdtype)
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
                         continue
@@ -321,7 +326,7 @@ class Engine:
                         lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd)
                 bwd_groups.append(('pool', n, pd, k))
             elif n.kind == 'head':
-                hd = HeadDesc(N, n.HW, n.C, n.x.buf.C, n.NC, _lib.BF16, 2.0)
+                hd = HeadDesc(N, n.HW, n.C, n.x.buf.C, n.NC, self.cdtype, 2.0)
                 wkey, bkey = n.key + '.weight', n.key + '.bias'
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
@@ -485,7 +490,7 @@ class Engine:
         if self.net.transform_input:
             sc = (C.c_float * 3)(0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5)
             sh = (C.c_float * 3)((0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5)
-        self.ctx.call('ifcbk_nchw_to_nhwc', _vp(x), N, 3, S, S, 8, _lib.BF16, sc, sh, _vp(self.act[self.net.input.id]),
+        self.ctx.call('ifcbk_nchw_to_nhwc', _vp(x), N, 3, S, S, 8, self.cdtype, sc, sh, _vp(self.act[self.net.input.id]),
                       self.stream())
         return N
 
@@ -495,7 +500,7 @@ class Engine:
         d = RoiDesc()
         d.n_img, d.S, d.in_channels, d.out_channels = n, self.net.S, in_channels, 8
         d.flip_bits_valid = 1 if flips is not None else 0
-        d.dtype = _lib.BF16
+        d.dtype = self.cdtype
         for k in range(3):
             d.mean[k] = 0.0 if mean is None else float(mean[k])
             d.std[k] = 1.0 if std is None else float(std[k])

@@ -49,10 +49,10 @@ class _NetFn(torch.autograd.Function):
 
 
 class HipBackbone(nn.Module):
-    def __init__(self, net, device=0, max_batch=None):
+    def __init__(self, net, device=0, max_batch=None, dtype='bf16'):
         super().__init__()
         max_batch = max_batch or 32
-        object.__setattr__(self, 'engine', Engine(net, device, max_batch))
+        object.__setattr__(self, 'engine', Engine(net, device, max_batch, dtype=dtype))
         object.__setattr__(self, 'net', net)
         eng = self.engine
         pmap = {}
@@ -117,7 +117,7 @@ class HipBackbone(nn.Module):
         return self._train_heads[0].logits[:N].clone()
 
 
-def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None):
+def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None, dtype='bf16'):
     """``neuston_models.py:22-45``.  Backbones on the HIP path: inception_v3, resnet18/34/50/101/152.
     ``pretrained=True`` cannot download ImageNet weights here (no torchvision / network): it switches on
     inception's ``transform_input`` exactly as torchvision does and expects a ``load_state_dict`` to follow.
@@ -126,7 +126,7 @@ def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, m
     if model_name in ('alexnet', 'squeezenet') or model_name.startswith(('vgg', 'densenet')):
         raise NotImplementedError('%s is accepted by the reference but not built on the MI355X path yet' % model_name)
     net = graph.build(model_name, num_o_classes, pretrained)
-    return HipBackbone(net, device, max_batch)
+    return HipBackbone(net, device, max_batch, dtype)
 
 
 class NeustonModel(nn.Module):
@@ -141,7 +141,8 @@ class NeustonModel(nn.Module):
         self.hparams = hparams
         self.criterion = nn.CrossEntropyLoss()
         mb = max_batch or getattr(hparams, 'batch_size', None) or 32
-        self.model = get_namebrand_model(hparams.MODEL, len(hparams.classes), hparams.pretrained, device, mb)
+        self.model = get_namebrand_model(hparams.MODEL, len(hparams.classes), hparams.pretrained, device, mb,
+                                         getattr(hparams, 'precision', 'bf16') or 'bf16')
         self.best_val_loss = np.inf
         self.best_epoch = 0
         self.agg_train_loss = 0.0

@@ -360,6 +360,7 @@ def argparse_nn(parser=None):
     common = parser.add_argument_group(title='NN Common Args', description=None)
     common.add_argument('--batch', dest='batch_size', metavar='SIZE', default=108, type=int, help='Number of images per batch. Defaults is 108')
     common.add_argument('--loaders', metavar='N', default=4, type=int, help='Number of data-loading threads. 4 per GPU is typical. Default is 4')
+    common.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16', help='(MI355X path, additive) activation storage / MFMA type: bf16 = performance mode (default), fp32 = parity mode matching the reference CPU arithmetic to 1e-3')
     argparse_nn_train(train)
     argparse_nn_run(run)
     return parser

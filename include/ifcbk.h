@@ -14,7 +14,9 @@
  *   - a ctx is thread-compatible (one caller at a time), one per (process, GPU).
  *   - activations are NHWC; `ld*` is the element stride between consecutive pixels so a tensor may be a
  *     channel slice of a wider (concat) buffer.  Channel counts, ld* and slice offsets are multiples of 8.
- *   - dtype: IFCBK_BF16 (2-byte storage, fp32 accumulate) is implemented; IFCBK_F32 is reserved.
+ *   - dtype: IFCBK_BF16 (2-byte storage, fp32 accumulate, v_mfma_f32_16x16x32_bf16) is the performance mode;
+ *     IFCBK_F32 (4-byte storage, v_mfma_f32_16x16x4_f32 = exact fp32 fma chain) is the parity mode.  Channel counts,
+ *     ld* and slice offsets are multiples of 16 bytes / element size (8 for bf16, 4 for f32).
  */
 #ifndef IFCBK_H
 #define IFCBK_H

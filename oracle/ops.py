@@ -12,7 +12,18 @@ import torch
 import torch.nn.functional as F
 
 
+STORAGE = 'bf16'      # 'bf16': emulate the HIP path's bf16 storage rounding; 'fp32': the reference's own arithmetic
+
+
+def set_storage(kind):
+    global STORAGE
+    assert kind in ('bf16', 'fp32')
+    STORAGE = kind
+
+
 def bf16_round(x):
+    if STORAGE == 'fp32':
+        return x
     return x.to(torch.bfloat16).to(torch.float32)
 
 
@@ -33,9 +44,13 @@ def bn_act_fwd(raw, gamma, beta, eps, relu, residual=None):
     return bf16_round(y), mean, var
 
 
-def bn_act_bwd(raw, gamma, beta, eps, relu, residual, gy):
+def bn_act_bwd(raw, gamma, beta, eps, relu, residual, gy, y_for_mask=None):
     """backward of bn_act_fwd at (raw, residual) for upstream gradient gy.
-    returns d_raw (bf16-rounded, as the HIP path stores it), dgamma, dbeta, dresidual (or None)."""
+    returns d_raw (bf16-rounded, as the HIP path stores it), dgamma, dbeta, dresidual (or None).
+    ``y_for_mask``: take the ReLU mask from this (the checked path's own) activation instead of recomputing it --
+    an element whose pre-activation is zero to within rounding may legitimately land on either side of the ReLU
+    kink under a different but equally valid evaluation order, and a few such elements dominate a 256-sample
+    channel sum; the forward comparison already bounds the activation itself."""
     raw = raw.clone().requires_grad_(True)
     g = gamma.clone().requires_grad_(True)
     b = beta.clone().requires_grad_(True)
@@ -44,7 +59,7 @@ def bn_act_bwd(raw, gamma, beta, eps, relu, residual, gy):
     if res is not None:
         y = y + res
     if relu:
-        y = F.relu(y)
+        y = y * (y_for_mask > 0).to(y.dtype) if y_for_mask is not None else F.relu(y)
     y.backward(gy)
     return bf16_round(raw.grad), g.grad, b.grad, (res.grad if res is not None else None)
 

@@ -50,7 +50,7 @@ def check_plan(hip, N, mask=None, verbose=False):
             st = eng.stats[n.st_off:n.st_off + 2 * n.K].cpu()
             upd('stats', max(rel(st[:n.K], mean), rel(st[n.K:], 1.0 / torch.sqrt(var + n.eps))), n.name)
             gy = grd(n.y)
-            d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy)
+            d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy, y_for_mask=act(n.y))
             upd('dgamma', rel(G[n.bn_key + '.weight'], dg), n.name)
             upd('dbeta', rel(G[n.bn_key + '.bias'], db), n.name)
             need_dx = not n.x.buf.is_input

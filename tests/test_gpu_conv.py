@@ -143,3 +143,44 @@ def test_conv_rejects_bad_desc(ctx):
     d = _desc(_lib, 1, 12, 8, 8, 16, 3, 3, 1, 1, 0, 0)      # C not a multiple of 8
     with pytest.raises(RuntimeError, match='multiples of 8'):
         ctx.call('ifcbk_conv2d_fwd', C.byref(d), None, None, None, None, None)
+
+
+@pytest.mark.parametrize('case', CASES[:10] + CASES[12:14])
+def test_conv_fp32_parity_mode(ctx, case):
+    """fp32 storage / v_mfma_f32_16x16x4_f32 path vs torch-CPU fp32 conv: 1e-5 relative."""
+    from ifcb_classifier_amd import _lib
+    from ifcb_classifier_amd._lib import ConvDesc
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    g = torch.Generator().manual_seed(7 + hash(case) % 1000)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(K, Cc, R, S, generator=g) * (1.0 / (Cc * R * S) ** 0.5)
+    P = (H + 2 * ph - R) // sh + 1
+    Q = (W + 2 * pw - S) // sw + 1
+    d = ConvDesc(N, H, W, Cc, Cc, K, R, S, sh, sw, ph, pw, P, Q, K, Cc, 1)
+    dy = torch.randn(N, K, P, Q, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, (sh, sw), (ph, pw))
+    yr.backward(dy)
+    st = _lib.cur_stream()
+    wm = w.permute(0, 2, 3, 1).contiguous().cuda()
+    wk = torch.empty(K, R, S, Cc, device='cuda')
+    wT = torch.empty(Cc, R, S, K, device='cuda')
+    ctx.call('ifcbk_weight_pack', C.byref(d), _lib.ptr(wm), _lib.ptr(wk), _lib.ptr(wT), st)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.full((N, P, Q, K), float('nan'), device='cuda')
+    mb = ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
+    part = torch.zeros(mb, 2, K, device='cuda')
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), _lib.ptr(xd), _lib.ptr(wk), _lib.ptr(y), _lib.ptr(part), st)
+    dx = torch.full((N, H, W, Cc), float('nan'), device='cuda')
+    ctx.call('ifcbk_conv2d_dgrad', C.byref(d), _lib.ptr(dyd), _lib.ptr(wT), _lib.ptr(dx), 0, st)
+    dw = torch.full((K, R, S, Cc), float('nan'), device='cuda')
+    ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
+    ctx.call('ifcbk_conv2d_wgrad', C.byref(d), _lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw), 0, st)
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    yh = y.cpu().permute(0, 3, 1, 2)
+    assert rel(yh, yr.detach()) < 1e-5
+    assert torch.allclose(part[:, 0].sum(0).cpu(), yh.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-5
+    assert rel(dw.cpu(), wr.grad.permute(0, 2, 3, 1)) < 1e-5
