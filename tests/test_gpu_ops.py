@@ -106,7 +106,9 @@ def test_nchw_to_nhwc_with_transform_input(ctx):
     ctx.call('ifcbk_nchw_to_nhwc', _lib.ptr(xd), 3, 3, 17, 19, 8, 0, sc, sh, _lib.ptr(y), _lib.cur_stream())
     torch.cuda.synchronize()
     ref = torch.stack([x[:, c] * sc[c] + sh[c] for c in range(3)], 1)
-    assert torch.equal(nchw(y)[:, :3], _bf(ref))
+    # the kernel contracts v*scale+shift into one fma: at most one bf16 ulp from torch's mul-then-add
+    assert (nchw(y)[:, :3] - _bf(ref)).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+    assert ((nchw(y)[:, :3] != _bf(ref)).float().mean().item()) < 0.01
     assert nchw(y)[:, 3:].abs().max().item() == 0
 
 
