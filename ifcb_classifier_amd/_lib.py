@@ -13,12 +13,13 @@ BF16, F32 = 0, 1
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
- OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE) = range(1, 21)
+ OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
+ OP_WEIGHT_PACK_MULTI) = range(1, 22)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
-            19: 'dropout_mask', 20: 'conv_fwd_affine'}
+            19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi'}
 
 
 class ConvDesc(C.Structure):
@@ -48,6 +49,11 @@ class RoiDesc(C.Structure):
                 ('tin_shift', C.c_float * 3)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w_master', C.c_void_p), ('w', C.c_void_p), ('wT', C.c_void_p), ('K', C.c_int32), ('RS', C.c_int32),
+                ('C', C.c_int32), ('Cw', C.c_int32), ('first_block', C.c_int64)]
+
+
 class _OpU(C.Union):
     _fields_ = [('conv', ConvDesc), ('bn', BnDesc), ('pool', PoolDesc), ('head', HeadDesc)]
 
@@ -72,6 +78,7 @@ _PROTOS = {
     'ifcbk_conv2d_wgrad_workspace': (_sz, [C.POINTER(ConvDesc)]),
     'ifcbk_conv2d_fwd_mblocks': (_i, [C.POINTER(ConvDesc)]),
     'ifcbk_weight_pack': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    'ifcbk_weight_pack_multi': (_i, [_vp, _vp, _i, C.c_int64, _i, _vp]),
     'ifcbk_bn_finalize': (_i, [_vp, C.POINTER(BnDesc), _vp, _i] + [_vp] * 9),
     'ifcbk_bn_apply': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'ifcbk_bn_bwd': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp,

@@ -418,7 +418,41 @@ __global__ void weight_pack_kernel(const float* wm, T* w, T* wT, int K, int RS, 
     w[i] = b;
     if (wT) wT[((int64_t)c * RS + (RS - 1 - rs)) * K + k] = b;
 }
+template <class T>
+__global__ __launch_bounds__(256) void weight_pack_multi_kernel(const ifcbk_pack_item* items, int n_items) {
+    // binary search: last item whose first_block <= blockIdx.x
+    int lo = 0, hi = n_items - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const ifcbk_pack_item it = items[lo];
+    const int64_t total = (int64_t)it.K * it.RS * it.C;
+    const int64_t i = (b - it.first_block) * 256 + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % it.C);
+    int64_t krs = i / it.C;
+    int rs = (int)(krs % it.RS);
+    int k = (int)(krs / it.RS);
+    float v = c < it.Cw ? it.w_master[krs * it.Cw + c] : 0.f;
+    T q = from_f32<T>(v);
+    ((T*)it.w)[i] = q;
+    if (it.wT) ((T*)it.wT)[((int64_t)c * it.RS + (it.RS - 1 - rs)) * it.K + k] = q;
+}
 }  // namespace
+
+extern "C" int ifcbk_weight_pack_multi(ifcbk_ctx* ctx, const ifcbk_pack_item* items_dev, int n_items, int64_t total_blocks,
+                                       int dtype, void* stream) {
+    if (!items_dev || n_items <= 0 || total_blocks <= 0 || total_blocks >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "weight_pack_multi: bad args");
+    if (dtype == IFCBK_F32)
+        hipLaunchKernelGGL(weight_pack_multi_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+    else if (dtype == IFCBK_BF16)
+        hipLaunchKernelGGL(weight_pack_multi_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+    else IFCBK_FAIL(ctx, IFCBK_EINVAL, "weight_pack_multi: bad dtype");
+    IFCBK_LAUNCH_CHECK(ctx, "weight_pack_multi");
+    return 0;
+}
 
 extern "C" int ifcbk_weight_pack(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const float* w_master, void* w, void* wT,
                                  void* stream) {

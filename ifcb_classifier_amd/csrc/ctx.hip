@@ -64,6 +64,8 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                            (int)o->i[0], (o->flags >> 2) & 1, st);
         case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
         case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
+        case IFCBK_OP_WEIGHT_PACK_MULTI:
+            return ifcbk_weight_pack_multi(c, (const ifcbk_pack_item*)p[0], (int)o->i[0], o->i[1], (int)o->i[2], st);
         case IFCBK_OP_WEIGHT_PACK: return ifcbk_weight_pack(c, &o->u.conv, (const float*)p[0], p[1], p[2], st);
         case IFCBK_OP_BN_FINALIZE:
             return ifcbk_bn_finalize(c, &o->u.bn, (const float*)p[0], (int)o->i[0], (const float*)p[1], (const float*)p[2],
@@ -185,6 +187,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_AVGPOOL_BWD: snprintf(name, cap, "avgpool_bwd_kernel"); break;
         case IFCBK_OP_ADAM: snprintf(name, cap, "adam_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK: snprintf(name, cap, "weight_pack_kernel"); break;
+        case IFCBK_OP_WEIGHT_PACK_MULTI: snprintf(name, cap, "weight_pack_multi_kernel"); break;
         default: break;
     }
     return IFCBK_OK;

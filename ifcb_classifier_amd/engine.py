@@ -381,6 +381,7 @@ class Engine:
         pl = PlanObj()
         pl.N = N
         pl.fwd_train, pl.fwd_eval, pl.bwd = Program(fwd_t), Program(fwd_e), Program(bwd)
+        pack = self._pack_multi(pack)
         pl.pack, pl.evalprep = Program(pack), Program(evalprep)
         # loss ops: CE(main) + 0.4*CE(aux)   (neuston_models.py:70-78)
         lossl = OpList()
@@ -420,6 +421,27 @@ class Engine:
         pl.bwd_list = bwd
         pl.ddp_segs = None
         return pl
+
+    def _pack_multi(self, pack):
+        """fold the per-conv weight_pack ops into ONE multi-tensor launch (device-side item table, built once)."""
+        import numpy as np
+        if getattr(self, '_pack_items', None) is None:
+            items = (_lib.PackItem * len(pack.ops))()
+            blk = 0
+            for k, o in enumerate(pack.ops):
+                d = o.u.conv
+                it = items[k]
+                it.w_master, it.w, it.wT = o.p[0], o.p[1], o.p[2]
+                it.K, it.RS, it.C, it.Cw = d.K, d.R * d.S, d.C, d.Cw
+                it.first_block = blk
+                blk += (d.K * d.R * d.S * d.C + 255) // 256
+            raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+            self._pack_items = torch.from_numpy(raw).to(self.dev)
+            self._pack_n, self._pack_blocks = len(pack.ops), blk
+        out = OpList()
+        out.add(_lib.OP_WEIGHT_PACK_MULTI, 'weight_pack', p=(_vp(self._pack_items),),
+                i=(self._pack_n, self._pack_blocks, self.cdtype))
+        return out
 
     def _op_param_offsets(self, o):
         """element offsets (into the flat gradient buffer) of the parameter tensors a backward op writes."""

@@ -87,6 +87,17 @@ int  ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc*);   /* rows of bn_part */
 int ifcbk_weight_pack(ifcbk_ctx*, const ifcbk_conv_desc*, const float* w_master, void* w, void* wT,
                       void* stream);
 
+/* all convs of a model in ONE launch: `items` is a DEVICE array built once by the host */
+typedef struct {
+    const float* w_master;   /* fp32 [K][R][S][Cw]                                                    */
+    void*   w;               /* shadow [K][R][S][C]                                                   */
+    void*   wT;              /* flipped/transposed shadow [C][R][S][K] or NULL                        */
+    int32_t K, RS, C, Cw;
+    int64_t first_block;     /* index of this item's first 256-thread block in the launch             */
+} ifcbk_pack_item;
+int ifcbk_weight_pack_multi(ifcbk_ctx*, const ifcbk_pack_item* items_dev, int n_items, int64_t total_blocks, int dtype,
+                            void* stream);
+
 /* ------------------------------------------------------------------ BatchNorm (+ReLU, +residual)
  * replaces aten::batch_norm / relu_ inside [TV] BasicConv2d and resnet blocks (neuston_models.py:66-68) */
 typedef struct {
@@ -196,7 +207,8 @@ enum {
     IFCBK_OP_BN_FINALIZE, IFCBK_OP_BN_APPLY, IFCBK_OP_BN_BWD,
     IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
-    IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE
+    IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
+    IFCBK_OP_WEIGHT_PACK_MULTI
 };
 typedef struct {
     int32_t kind;
