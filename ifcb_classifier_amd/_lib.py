@@ -14,12 +14,12 @@ BF16, F32 = 0, 1
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
- OP_WEIGHT_PACK_MULTI) = range(1, 22)
+ OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG) = range(1, 23)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
-            19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi'}
+            19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad'}
 
 
 class ConvDesc(C.Structure):
@@ -51,7 +51,7 @@ class RoiDesc(C.Structure):
 
 class PackItem(C.Structure):
     _fields_ = [('w_master', C.c_void_p), ('w', C.c_void_p), ('wT', C.c_void_p), ('K', C.c_int32), ('RS', C.c_int32),
-                ('C', C.c_int32), ('Cw', C.c_int32), ('first_block', C.c_int64)]
+                ('C', C.c_int32), ('Cw', C.c_int32), ('first_block', C.c_int64), ('wT_ld', C.c_int32), ('pad_', C.c_int32)]
 
 
 class _OpU(C.Union):
@@ -75,6 +75,8 @@ _PROTOS = {
     'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'ifcbk_conv2d_dgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_wgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    'ifcbk_conv2d_wgrad_segments': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp]),
+    'ifcbk_bn_finalize_ld': (_i, [_vp, C.POINTER(BnDesc), _vp, _i, _i] + [_vp] * 9),
     'ifcbk_conv2d_wgrad_workspace': (_sz, [C.POINTER(ConvDesc)]),
     'ifcbk_conv2d_fwd_mblocks': (_i, [C.POINTER(ConvDesc)]),
     'ifcbk_weight_pack': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),

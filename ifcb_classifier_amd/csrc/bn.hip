@@ -7,7 +7,7 @@ namespace {
 
 // ---------------------------------------------------------------- finalize
 // one block per 16 channels; 64 row groups stride over the per-M-block partials written by the conv epilogue
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, int mblocks, int C, double invM,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, int mblocks, int ldp, int C, double invM,
                                                             double unbias, const float* gamma, const float* beta,
                                                             float* rmean, float* rvar, float* mean_o, float* invstd_o,
                                                             float* scale, float* shift, float eps, float momentum) {
@@ -17,8 +17,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
     double a = 0.0, b = 0.0;
     if (ch < C) {
         for (int mb = rg; mb < mblocks; mb += 64) {
-            a += (double)part[((size_t)mb * 2 + 0) * C + ch];
-            b += (double)part[((size_t)mb * 2 + 1) * C + ch];
+            a += (double)part[((size_t)mb * 2 + 0) * ldp + ch];
+            b += (double)part[((size_t)mb * 2 + 1) * ldp + ch];
         }
     }
     s1[rg][c] = a;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
 }
 
 // stage 0 for layers with many M-blocks: chunk `blockIdx.y` of the partial rows -> one fp32 row (double accumulate)
-__global__ __launch_bounds__(256) void bn_prereduce_kernel(const float* part, int mblocks, int C, int rows_per_chunk,
+__global__ __launch_bounds__(256) void bn_prereduce_kernel(const float* part, int mblocks, int ldp, int C, int rows_per_chunk,
                                                            float* out) {
     __shared__ double s[2][4][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void bn_prereduce_kernel(const float* part, in
     double a = 0.0, b = 0.0;
     if (ch < C)
         for (int mb = r0 + rg; mb < r1; mb += 4) {
-            a += (double)part[((size_t)mb * 2 + 0) * C + ch];
-            b += (double)part[((size_t)mb * 2 + 1) * C + ch];
+            a += (double)part[((size_t)mb * 2 + 0) * ldp + ch];
+            b += (double)part[((size_t)mb * 2 + 1) * ldp + ch];
         }
     s[0][rg][c] = a;
     s[1][rg][c] = b;
@@ -332,8 +332,15 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
 extern "C" int ifcbk_bn_finalize(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const float* part, int mblocks,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    return ifcbk_bn_finalize_ld(ctx, d, part, mblocks, 0, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, stream);
+}
+
+extern "C" int ifcbk_bn_finalize_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const float* part, int mblocks, int part_ld,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float* mean, float* invstd, float* scale, float* shift, void* stream) {
     if (!d || d->C <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_finalize: bad desc");
     hipStream_t st = (hipStream_t)stream;
+    int ldp = part_ld > 0 ? part_ld : d->C;
     if (part) {
         double M = (double)d->M;
         double unbias = d->M > 1 ? M / (M - 1.0) : 1.0;
@@ -343,13 +350,14 @@ extern "C" int ifcbk_bn_finalize(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const f
             int nchunk = cdiv(mblocks, rpc);
             size_t need = (size_t)nchunk * 2 * d->C * sizeof(float);
             if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_finalize: workspace %zu > reserved %zu", need, ctx->ws_bytes);
-            hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(d->C, 64), nchunk), dim3(256), 0, st, part, mblocks, d->C, rpc,
+            hipLaunchKernelGGL(bn_prereduce_kernel, dim3(cdiv(d->C, 64), nchunk), dim3(256), 0, st, part, mblocks, ldp, d->C, rpc,
                                (float*)ctx->ws);
             IFCBK_LAUNCH_CHECK(ctx, "bn_prereduce");
             part = (const float*)ctx->ws;
             mblocks = nchunk;
+            ldp = d->C;
         }
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d->C, 16)), dim3(1024), 0, st, part, mblocks, d->C, 1.0 / M,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d->C, 16)), dim3(1024), 0, st, part, mblocks, ldp, d->C, 1.0 / M,
                            unbias, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, d->eps,
                            d->momentum);
     } else {

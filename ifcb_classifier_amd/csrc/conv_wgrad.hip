@@ -281,17 +281,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_f32(WgradArgs a) {
 
 // dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]; 64 outputs x 4 split lanes per block, the 4 lane sums are
 // combined in a fixed order (bitwise reproducible)
+// (k_off, Kseg): the rows [k_off, k_off+Kseg) of a horizontally fused conv go to their own destination tensor
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw,
-                                                    int accumulate) {
+                                                    int accumulate, int k_off, int Kseg) {
     __shared__ float part[4][64];
-    const int64_t total = (int64_t)K * RS * Cw;
+    const int64_t total = (int64_t)Kseg * RS * Cw;
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float s = 0.f;
     if (i < total) {
         int cw = (int)(i % Cw);
         int64_t krs = i / Cw;
-        const float* src = slab + krs * C + cw;
+        const float* src = slab + ((int64_t)k_off * RS + krs) * C + cw;
         const int64_t stride = (int64_t)K * RS * C;
         float s0 = 0.f, s1 = 0.f;
         int sp = sg;
@@ -356,8 +357,27 @@ int ifcbk_conv_wgrad_mt(int K) { return pick_mt(K); }
 
 extern "C" size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc* d) { return make_plan(d).ws; }
 
+static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, int nseg, float* const* dws,
+                      const int* kseg, int accumulate, void* stream);
+
 extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* dw,
                                   int accumulate, void* stream) {
+    if (!d) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: null desc");
+    int k = d->K;
+    return wgrad_impl(ctx, d, x, dy, 1, &dw, &k, accumulate, stream);
+}
+
+extern "C" int ifcbk_conv2d_wgrad_segments(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, int nseg,
+                                           float* const* dws, const int32_t* kseg, int accumulate, void* stream) {
+    if (!d || nseg < 1 || nseg > 8 || !dws || !kseg) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_segments: bad args");
+    int sum = 0;
+    for (int i = 0; i < nseg; ++i) sum += kseg[i];
+    if (sum != d->K) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_segments: segment sizes sum to %d, K=%d", sum, d->K);
+    return wgrad_impl(ctx, d, x, dy, nseg, dws, kseg, accumulate, stream);
+}
+
+static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, int nseg, float* const* dws,
+                      const int* kseg, int accumulate, void* stream) {
     if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad: dtype must be bf16 or f32");
     const int ce = dtype_chunk(d->dtype), es = dtype_esize(d->dtype);
     if (d->C % ce || d->K % ce || d->ldx % ce || d->ldy % ce) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad: channels must be multiples of %d", ce);
@@ -394,10 +414,14 @@ extern "C" int ifcbk_conv2d_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
         }
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
-    int64_t total = (int64_t)d->K * d->R * d->S * d->Cw;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 64)), dim3(256), 0, st, (const float*)ctx->ws, dw, p.nsplit,
-                       d->K, d->R * d->S, d->C, d->Cw, accumulate);
-    IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
+    int k_off = 0;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        int64_t total = (int64_t)kseg[sgi] * d->R * d->S * d->Cw;
+        hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 64)), dim3(256), 0, st, (const float*)ctx->ws, dws[sgi], p.nsplit,
+                           d->K, d->R * d->S, d->C, d->Cw, accumulate, k_off, kseg[sgi]);
+        IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
+        k_off += kseg[sgi];
+    }
     return 0;
 }
 
@@ -438,7 +462,8 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(const ifcbk_pack
     float v = c < it.Cw ? it.w_master[krs * it.Cw + c] : 0.f;
     T q = from_f32<T>(v);
     ((T*)it.w)[i] = q;
-    if (it.wT) ((T*)it.wT)[((int64_t)c * it.RS + (it.RS - 1 - rs)) * it.K + k] = q;
+    const int ldT = it.wT_ld > 0 ? it.wT_ld : it.K;      // horizontally fused convs share one [C][RS][Ktot] dgrad filter
+    if (it.wT) ((T*)it.wT)[((int64_t)c * it.RS + (it.RS - 1 - rs)) * ldT + k] = q;
 }
 }  // namespace
 

@@ -64,11 +64,18 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                            (int)o->i[0], (o->flags >> 2) & 1, st);
         case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
         case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
+        case IFCBK_OP_CONV_WGRAD_SEG: {
+            float* dws[4];
+            int32_t ks[4];
+            int ns = 0;
+            for (int k = 0; k < 4 && o->i[k] > 0; ++k) { dws[ns] = (float*)p[2 + k]; ks[ns] = (int32_t)o->i[k]; ++ns; }
+            return ifcbk_conv2d_wgrad_segments(c, &o->u.conv, p[0], p[1], ns, dws, ks, acc, st);
+        }
         case IFCBK_OP_WEIGHT_PACK_MULTI:
             return ifcbk_weight_pack_multi(c, (const ifcbk_pack_item*)p[0], (int)o->i[0], o->i[1], (int)o->i[2], st);
         case IFCBK_OP_WEIGHT_PACK: return ifcbk_weight_pack(c, &o->u.conv, (const float*)p[0], p[1], p[2], st);
         case IFCBK_OP_BN_FINALIZE:
-            return ifcbk_bn_finalize(c, &o->u.bn, (const float*)p[0], (int)o->i[0], (const float*)p[1], (const float*)p[2],
+            return ifcbk_bn_finalize_ld(c, &o->u.bn, (const float*)p[0], (int)o->i[0], (int)o->i[1], (const float*)p[1], (const float*)p[2],
                                      (float*)p[3], (float*)p[4], (float*)p[5], (float*)p[6], (float*)p[7], (float*)p[8], st);
         case IFCBK_OP_BN_APPLY:
             return ifcbk_bn_apply(c, &o->u.bn, p[0], (const float*)p[1], (const float*)p[2], p[3], (int)o->i[0], p[4], st);
@@ -177,7 +184,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %s>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, (d.stride_h == 2 || d.stride_w == 2) ? "true" : "false");
             break;
         }
-        case IFCBK_OP_CONV_WGRAD: snprintf(name, cap, "conv_wgrad_bf16<%d>", ifcbk_conv_wgrad_mt(o->u.conv.K)); break;
+        case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: snprintf(name, cap, "conv_wgrad_bf16<%d>", ifcbk_conv_wgrad_mt(o->u.conv.K)); break;
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;
@@ -196,7 +203,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
 extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
     double fl = 0, by = 0;
     switch (o->kind) {
-        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD: {
+        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD:
+        case IFCBK_OP_CONV_WGRAD_SEG: {
             const ifcbk_conv_desc& d = o->u.conv;
             double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
             fl = 2.0 * mac;

@@ -7,6 +7,7 @@ streams.  The HIP library is mandatory -- there is no CPU fallback in this modul
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -85,6 +86,7 @@ class Engine:
         self.packed = False
         self.eval_stats_ready = False
         self.dropout_seed = 0x1234
+        self.fuse_siblings = os.environ.get('IFCBK_FUSE_SIBLINGS', '1') != '0'
         self.dropout_calls = 0
         self.external_mask = None
         self._plans = {}
@@ -129,15 +131,58 @@ class Engine:
         self.convs = convs
         self.nbt = torch.zeros(len(convs), dtype=torch.int64, device=dev)        # num_batches_tracked (all BNs)
         # bf16 shadows + per-BN statistics
+        # horizontal fusion: sibling 1x1 convs that read the same tensor become ONE GEMM (filters concatenated along K)
+        # in the training forward / dgrad / wgrad; their BatchNorms stay per branch on channel slices.
+        class Group:
+            pass
+        self.groups = []
+        bykey = {}
+        if self.fuse_siblings:
+            for n in convs:
+                n.group = None
+                if (n.R == 1 and n.S == 1 and n.sh == 1 and n.sw == 1 and n.ph == 0 and n.pw == 0 and n.x.is_full
+                        and not n.x.buf.is_input and n.residual is None and n.relu):
+                    bykey.setdefault(n.x.buf.id, []).append(n)
+        for members in bykey.values():
+            if 2 <= len(members) <= 4:
+                g = Group()
+                g.members, g.x = members, members[0].x
+                g.Ktot = sum(m.K for m in members)
+                off = 0
+                for m in members:
+                    m.group, m.koff = g, off
+                    off += m.K
+                self.groups.append(g)
+        for n in convs:
+            if not hasattr(n, 'group'):
+                n.group = None
         soff = 0
         stoff = 0
+        done = set()
         for n in convs:
-            n.w_off = soff
-            soff += n.K * n.R * n.S * n.x.C
-            n.wT_off = soff
-            soff += n.K * n.R * n.S * n.x.C
-            n.st_off = stoff
-            stoff += 6 * n.K          # mean, invstd, scale, shift, eval_scale, eval_shift
+            g = n.group
+            if g is None:
+                n.w_off = soff
+                soff += n.K * n.R * n.S * n.x.C
+                n.wT_off = soff
+                soff += n.K * n.R * n.S * n.x.C
+                n.wT_ld = 0
+                n.st_off, n.st_ld = stoff, n.K
+                stoff += 6 * n.K          # mean, invstd, scale, shift, eval_scale, eval_shift
+            elif id(g) not in done:
+                done.add(id(g))
+                Cin = g.x.C
+                g.w_off = soff                      # [Ktot][Cin]: member rows are contiguous
+                soff += g.Ktot * Cin
+                g.wT_off = soff                     # [Cin][Ktot]: members own column slices
+                soff += g.Ktot * Cin
+                g.st_off = stoff                    # 6 arrays of Ktot
+                stoff += 6 * g.Ktot
+                for m in g.members:
+                    m.w_off = g.w_off + m.koff * Cin
+                    m.wT_off = g.wT_off + m.koff
+                    m.wT_ld = g.Ktot
+                    m.st_off, m.st_ld = g.st_off + m.koff, g.Ktot
         self.Wsh = torch.zeros(soff, dtype=self.tdtype, device=dev)
         self.stats = torch.zeros(stoff, dtype=torch.float32, device=dev)
 
@@ -183,8 +228,15 @@ class Engine:
         bf = self.tdtype
         self.act = {}
         self.grad = {}
+        grouped_raw = {m.raw.id: m for g in self.groups for m in g.members}
         for b in net.bufs:
+            if b.id in grouped_raw:
+                continue                              # lives inside the group's merged raw tensor
             self.act[b.id] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
+        for g in self.groups:
+            g.raw = torch.zeros(N, g.x.H, g.x.W, g.Ktot, dtype=bf, device=dev)
+            for m in g.members:
+                self.act[m.raw.id] = g.raw[..., m.koff:m.koff + m.K]        # strided view (tests / debugging)
         need_grad = set()
         for n in net.nodes:
             if getattr(n, 'kind', '') == 'conv':
@@ -201,7 +253,10 @@ class Engine:
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
         max_raw = max(n.P * n.Q * n.K for n in self.convs)
         self.draw = torch.zeros(N * max_raw, dtype=bf, device=dev)
-        mb = max(self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs)
+        gmax = max([g.x.H * g.x.W * g.Ktot for g in self.groups] + [0])
+        self.draw_group = torch.zeros(max(1, N * gmax), dtype=bf, device=dev)
+        mb = max([self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs] +
+                 [self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._group_desc(g, N))) * 2 * g.Ktot for g in self.groups])
         self.bn_part = torch.zeros(mb, dtype=torch.float32, device=dev)
         self.argmax = {}
         for k, n in enumerate(net.nodes):
@@ -224,6 +279,8 @@ class Engine:
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
             M = N * n.P * n.Q
             ws = max(ws, (((M + 1023) // 1024) * 2 * n.K + 2 * n.K) * 4)
+        for g in self.groups:
+            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, N))))
         self.ctx.reserve(ws)
 
     def activation_bytes(self):
@@ -236,6 +293,10 @@ class Engine:
         return ConvDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.K, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q,
                         n.y.buf.C, n.Cw, self.cdtype)
 
+    def _group_desc(self, g, N):
+        x = g.x
+        return ConvDesc(N, x.H, x.W, x.C, x.buf.C, g.Ktot, 1, 1, 1, 1, 0, 0, x.H, x.W, g.Ktot, x.C, self.cdtype)
+
     def _aptr(self, view, grad=False):
         t = (self.grad if grad else self.act)[view.buf.id]
         return _vp(t, self.esize * view.coff)
@@ -245,7 +306,13 @@ class Engine:
         return _vp(getattr(self, which), 4 * o)
 
     def _stat(self, n, k):
-        return _vp(self.stats, 4 * (n.st_off + k * n.K))
+        return _vp(self.stats, 4 * (n.st_off + k * n.st_ld))
+
+    def _raw_ptr(self, n):
+        """(pointer, pixel stride) of a conv's raw output -- a channel slice of the merged tensor for fused siblings"""
+        if n.group is not None:
+            return _vp(n.group.raw, self.esize * n.koff), n.group.Ktot
+        return _vp(self.act[n.raw.id]), n.K
 
     # ------------------------------------------------------------------ programs
     def plan(self, N):
@@ -273,14 +340,16 @@ class Engine:
                 M = N * n.P * n.Q
                 d = self._conv_desc(n, N)
                 # forward conv writes the raw output (own buffer, ld = K)
+                raw, ldraw = self._raw_ptr(n)
                 dfw = ConvDesc.from_buffer_copy(d)
-                dfw.ldy = n.K
-                raw = _vp(self.act[n.raw.id])
+                dfw.ldy = ldraw
                 wk = _vp(self.Wsh, self.esize * n.w_off)
                 wT = _vp(self.Wsh, self.esize * n.wT_off)
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 mb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
-                bnd = BnDesc(M, n.K, n.K, n.y.buf.C, 1 if n.relu else 0, self.cdtype, n.eps, 0.1)
+                bnd = BnDesc(M, n.K, ldraw, n.y.buf.C, 1 if n.relu else 0, self.cdtype, n.eps, 0.1)
+                g = n.group
+                first_of_group = g is not None and g.members[0] is n
                 res = self._aptr(n.residual) if n.residual is not None else None
                 ldr = n.residual.buf.C if n.residual is not None else 0
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
@@ -291,6 +360,27 @@ class Engine:
                         lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
                                 p=(self._aptr(n.x), wk, self._aptr(n.y), self._stat(n, 4), self._stat(n, 5), res),
                                 i=(ldr,), flags=4 if n.relu else 0, conv=d)
+                        continue
+                    if g is not None:
+                        if not first_of_group:
+                            continue                      # emitted with the group's first member
+                        # ONE GEMM for all sibling 1x1 convs, then each branch's BN on its channel slice
+                        gd = self._group_desc(g, N)
+                        gmb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(gd))
+                        lst.add(_lib.OP_CONV_FWD, '+'.join(m.name for m in g.members),
+                                p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), _vp(g.raw), _vp(self.bn_part)),
+                                conv=gd)
+                        for m in g.members:
+                            mbk = m.bn_key
+                            mraw, mld = self._raw_ptr(m)
+                            mbnd = BnDesc(M, m.K, mld, m.y.buf.C, 1, self.cdtype, m.eps, 0.1)
+                            lst.add(_lib.OP_BN_FINALIZE, m.name,
+                                    p=(_vp(self.bn_part, 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
+                                       _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
+                                       self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
+                                    i=(gmb, g.Ktot), bn=mbnd)
+                            lst.add(_lib.OP_BN_APPLY, m.name,
+                                    p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd)
                         continue
                     lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part) if train else None),
                             conv=dfw)
@@ -308,9 +398,9 @@ class Engine:
                                 _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
                                 None, None, self._stat(n, 4), self._stat(n, 5)), i=(0,), bn=bnd)
                 needs_dgrad = not n.x.buf.is_input
-                pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), conv=d)
+                pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), i=(n.wT_ld,), conv=d)
                 # ---- backward of this node
-                draw = _vp(self.draw)
+                draw = _vp(self.draw) if g is None else _vp(self.draw_group, self.esize * n.koff)
                 dres, lddres, dres_acc = None, 0, 0
                 # (flags resolved later, in reverse order) -> store a closure
                 bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad))
@@ -363,11 +453,26 @@ class Engine:
                     assert n.residual.is_full
                     dres_acc = acc_flag(n.residual.buf)
                     dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
+                grp = n.group
+                rawp, _ld = self._raw_ptr(n)
                 bwd.add(_lib.OP_BN_BWD, n.name,
-                        p=(_vp(self.act[n.raw.id]), self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
+                        p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
                            self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
                            self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
-                        i=(n.y.buf.C, n.K, lddres), flags=dres_acc, bn=bnd)
+                        i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd)
+                if grp is not None:
+                    # fused siblings: every member's d(raw) lands in its slice of the merged scratch; the member that
+                    # comes FIRST in forward order is the last one here and launches the single wgrad + dgrad
+                    if grp.members[0] is n:
+                        gd = self._group_desc(grp, N)
+                        gp = [_vp(self.draw_group)] + [self._pptr(m.conv_key + '.weight', 'G') for m in grp.members]
+                        bwd.add(_lib.OP_CONV_WGRAD_SEG, '+'.join(m.name for m in grp.members),
+                                p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd)
+                        acc = acc_flag(grp.x.buf)
+                        bwd.add(_lib.OP_CONV_DGRAD, '+'.join(m.name for m in grp.members),
+                                p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
+                                flags=acc, conv=gd)
+                    continue
                 dbw = ConvDesc.from_buffer_copy(d)
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
                 bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw)
@@ -433,6 +538,7 @@ class Engine:
                 it = items[k]
                 it.w_master, it.w, it.wT = o.p[0], o.p[1], o.p[2]
                 it.K, it.RS, it.C, it.Cw = d.K, d.R * d.S, d.C, d.Cw
+                it.wT_ld = int(o.i[0])
                 it.first_block = blk
                 blk += (d.K * d.R * d.S * d.C + 255) // 256
             raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
@@ -448,6 +554,8 @@ class Engine:
         base = self.G.data_ptr()
         if o.kind == _lib.OP_CONV_WGRAD:
             return [(o.p[2] - base) // 4]
+        if o.kind == _lib.OP_CONV_WGRAD_SEG:
+            return [(o.p[2 + k] - base) // 4 for k in range(4) if o.i[k] > 0]
         if o.kind == _lib.OP_BN_BWD:
             return [(o.p[8] - base) // 4, (o.p[9] - base) // 4]
         if o.kind == _lib.OP_HEAD_BWD:

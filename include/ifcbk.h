@@ -80,6 +80,11 @@ int ifcbk_conv2d_dgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const
  * deterministic split-K through the ctx workspace.                                                  */
 int ifcbk_conv2d_wgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* dy, float* dw,
                        int accumulate, void* stream);
+/* horizontally fused convs (siblings reading the same input, filters concatenated along K): ONE gradient GEMM over
+ * the concatenated dy, whose row segments kseg[i] are written to their own master-gradient tensors dws[i]
+ * (host arrays, nseg <= 8).                                                                                        */
+int ifcbk_conv2d_wgrad_segments(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* dy, int nseg,
+                                float* const* dws, const int32_t* kseg, int accumulate, void* stream);
 size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc*);
 int  ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc*);   /* rows of bn_part */
 /* master fp32 [K][R][S][Cw] -> bf16 shadow [K][R][S][C] (zero padded) and, if wT!=NULL, the flipped
@@ -94,6 +99,8 @@ typedef struct {
     void*   wT;              /* flipped/transposed shadow [C][R][S][K] or NULL                        */
     int32_t K, RS, C, Cw;
     int64_t first_block;     /* index of this item's first 256-thread block in the launch             */
+    int32_t wT_ld;           /* 0: K; >0: row stride of wT (this conv is a K-slice of a fused filter)  */
+    int32_t pad_;
 } ifcbk_pack_item;
 int ifcbk_weight_pack_multi(ifcbk_ctx*, const ifcbk_pack_item* items_dev, int n_items, int64_t total_blocks, int dtype,
                             void* stream);
@@ -112,6 +119,10 @@ typedef struct {
 /* train: part[mblocks][2][C] -> mean/invstd -> scale = g*invstd, shift = b - mean*scale;
  * running_mean/var updated with momentum (unbiased var), as torch.nn.BatchNorm2d does.
  * eval (part==NULL): scale/shift from the running statistics.                                       */
+/* part_ld (ifcbk_bn_finalize_ld): row stride of `part` when the BN owns a channel slice of a fused conv's partials */
+int ifcbk_bn_finalize_ld(ifcbk_ctx*, const ifcbk_bn_desc*, const float* part, int mblocks, int part_ld,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         float* mean, float* invstd, float* scale, float* shift, void* stream);
 int ifcbk_bn_finalize(ifcbk_ctx*, const ifcbk_bn_desc*, const float* part, int mblocks,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
@@ -208,7 +219,7 @@ enum {
     IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
-    IFCBK_OP_WEIGHT_PACK_MULTI
+    IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG
 };
 typedef struct {
     int32_t kind;

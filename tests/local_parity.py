@@ -42,13 +42,14 @@ def check_plan(hip, N, mask=None, verbose=False):
             w = P[n.conv_key + '.weight']
             gamma, beta = P[n.bn_key + '.weight'], P[n.bn_key + '.bias']
             stride, pad = (n.sh, n.sw), (n.ph, n.pw)
-            raw_h = _nchw(eng.act[n.raw.id], n.raw.full(), N)
+            raw_h = eng.act[n.raw.id][:N].float().cpu().permute(0, 3, 1, 2).contiguous()
             upd('raw', rel(raw_h, O.conv_raw(x, w, stride, pad)), n.name)
             res = act(n.residual) if n.residual is not None else None
             y_ref, mean, var = O.bn_act_fwd(raw_h, gamma, beta, n.eps, n.relu, res)
             upd('y', rel(act(n.y), y_ref), n.name)
-            st = eng.stats[n.st_off:n.st_off + 2 * n.K].cpu()
-            upd('stats', max(rel(st[:n.K], mean), rel(st[n.K:], 1.0 / torch.sqrt(var + n.eps))), n.name)
+            st_mean = eng.stats[n.st_off:n.st_off + n.K].cpu()
+            st_is = eng.stats[n.st_off + n.st_ld:n.st_off + n.st_ld + n.K].cpu()
+            upd('stats', max(rel(st_mean, mean), rel(st_is, 1.0 / torch.sqrt(var + n.eps))), n.name)
             gy = grd(n.y)
             d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy, y_for_mask=act(n.y))
             upd('dgamma', rel(G[n.bn_key + '.weight'], dg), n.name)
