@@ -58,7 +58,7 @@ def host_cores():
 def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
     """the reference's CPU path restated by the oracle: PIL L->RGB->resize->ToTensor per ROI, then the
     fp32 torch-CPU train step (loss = CE + 0.4 CE_aux, Adam 1e-3; neuston_models.py:63-86).  Bounded: one
-    warm-up step, then steps until ~budget_s of CPU work (at least 1, at most 5)."""
+    warm-up step, then steps until ~15 s of timed CPU work (at least 1 step; total bounded by budget_s)."""
     import numpy as np
     from PIL import Image
     from oracle import tv_models
@@ -90,12 +90,16 @@ def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
     step()
     warm = time.perf_counter() - t0
     print('[cpu_baseline] warm-up step of batch %d on %d threads: %.1f s' % (batch, cores, warm), file=sys.stderr, flush=True)
-    steps = int(max(1, min(5, (budget_s - warm) // max(warm, 1e-3))))
+    target = min(15.0, max(1.0, budget_s - warm))      # ~15 s of timed CPU work, never more than budget_s in total
+    steps = 0
     t0 = time.perf_counter()
-    for k in range(steps):
+    while True:
         step()
-        print('[cpu_baseline] step %d/%d' % (k + 1, steps), file=sys.stderr, flush=True)
-    dt = time.perf_counter() - t0
+        steps += 1
+        dt = time.perf_counter() - t0
+        print('[cpu_baseline] step %d, %.1f s' % (steps, dt), file=sys.stderr, flush=True)
+        if dt >= target or steps >= 64 or dt + dt / steps > budget_s:
+            break
     return dict(value=round(batch * steps / dt, 3), unit='images/s', cores=cores, kind='port',
                 sample='%d train steps of batch %d after 1 warm-up (PIL resize + fp32 torch-CPU oracle fwd/bwd/Adam), %.1f s'
                        % (steps, batch, dt))
@@ -233,8 +237,15 @@ def main():
             dom = max(conv, key=lambda k: conv[k]['ms'])
             d = conv[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            traffic = None
+            try:        # HBM bytes per launch of the same kernel from the committed PMC passes (scripts/collect_traffic.py)
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))['kernels']
+                traffic = round(tj[dom]['hbm_bytes_per_launch'])
+            except Exception:
+                pass
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                               'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']),
                                'avg_launch_ms': round(d['ms'] / d['launches'], 5), 'launches': d['launches'],
                                'flops_per_launch': d['flops'] / d['launches']}
             call = sum(v['flops'] for v in conv.values()) / (sum(v['ms'] for v in conv.values()) * 1e-3) / 1e12

@@ -278,7 +278,7 @@ class Engine:
             d = self._conv_desc(n, N)
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
             M = N * n.P * n.Q
-            ws = max(ws, (((M + 1023) // 1024) * 2 * n.K + 2 * n.K) * 4)
+            ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         for g in self.groups:
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, N))))
         self.ctx.reserve(ws)
@@ -290,6 +290,13 @@ class Engine:
 
     # ------------------------------------------------------------------ descriptors
     def _conv_desc(self, n, N):
+        if (n.R * n.S > 1 and n.R == n.x.H and n.S == n.x.W and n.ph == 0 and n.pw == 0 and n.P == 1 and n.Q == 1
+                and n.x.is_full and n.Cw == n.x.C):
+            # the filter covers the whole input (inception AuxLogits.conv1, 5x5 on 5x5): a plain GEMM.  Lower it as a
+            # 1x1 conv over the flattened pixel -- KRSC weights and NHWC activations already have that layout -- so
+            # dgrad does not walk 25 taps of which one is valid per pixel
+            CC = n.R * n.S * n.x.C
+            return ConvDesc(N, 1, 1, CC, CC, n.K, 1, 1, 1, 1, 0, 0, 1, 1, n.y.buf.C, CC, self.cdtype)
         return ConvDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.K, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q,
                         n.y.buf.C, n.Cw, self.cdtype)
 
