@@ -40,6 +40,7 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 // round-to-nearest-even, NaN preserved (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
@@ -102,7 +103,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const fastdiv_t& f) {
 
 int ifcbk_conv_fwd_nt(int K);
 int ifcbk_conv_fwd_wm(int M, int K);
-int ifcbk_conv_wgrad_mt(int K);
+void ifcbk_conv_wgrad_shape(const ifcbk_conv_desc* d, int* mt, int* cols);
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Bijective remap of the linear
 // block id so that every XCD works on ONE contiguous range of logical tiles: neighbouring tiles (which share
 // input rows / operand panels) then hit the same L2.  Speed only -- any placement is correct.

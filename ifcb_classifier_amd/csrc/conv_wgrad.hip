@@ -9,6 +9,7 @@
 // Split-K over pixel ranges with fp32 partial slabs in the ctx workspace, summed in a fixed order by
 // wgrad_reduce (bitwise reproducible; no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,25 +36,34 @@ constexpr int BNW = 128;    // (r,s,c) columns per block
 constexpr int TW = 128;     // LDS image width (elements) of BOTH tiles: [BKP rows][16 chunks of 16 B]
 constexpr int TILE = BKP * TW;
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ s16x4_t tr_read(const bf16_t* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-}
-// Both tiles are pixel-major (the reduction index is the ROW), 256-byte rows, filled by LDS-DMA.  16-byte
-// chunk c of row r lives at physical chunk c ^ ((r & 7) << 1): the 8 rows one half-wave touches in a
-// ds_read_b64_tr_b16 then fall into 8 different 32-byte bank slots (conflict-free transposing reads).
-__device__ __forceinline__ const bf16_t* tr_addr(const bf16_t* tile, int row, int col) {
-    int c16 = col >> 3;
-    return tile + row * TW + ((c16 ^ ((row & 7) << 1)) << 3) + (col & 7);
-}
+// ---------------------------------------------------------------- row-major tiles (K >= 96)
+// Both tiles are pixel-major (the reduction index is the ROW), 256-byte rows, filled by LDS-DMA: one wave-instruction
+// = 4 pixels x 256 contiguous bytes = whole cache lines.  16-byte chunk c of row r lives at physical chunk
+// c ^ ((r & 7) << 1): the 8 rows one half-wave touches in a ds_read_b64_tr_b16 then fall into 8 different 32-byte
+// bank slots (conflict-free transposing reads).
+//
+// What the first generation of this kernel taught (rocprofv3 SQ counters + s_memtime stamps on Mixed_6e 7x1, kept in
+// DESIGN.md): it issued 11.5 VALU instructions per MFMA (per-lane pixel decode for every DMA row group, swizzled
+// fragment addresses recomputed per read) -- the SIMDs were ~90 % busy ISSUING -- and the compiler put
+// s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every step (it orders every LDS access it can see
+// behind ALL pending LDS-DMA), so the prefetch of tile k+1 never overlapped the math on tile k.  Hence:
+//   * a wave's 16 pixels of a step are decoded ONCE (lane = pixel) into a 16-entry LDS table {h0, w0, x offset,
+//     dy offset}; the four DMA row groups read their entry back with one broadcast ds_read_b128 each,
+//   * the swizzled fragment addresses are per-lane constants (one VGPR per 16-column tile) and every
+//     ds_read_b64_tr_b16 uses an immediate offset for (stage, tile, k half) -- the step loop is unrolled by two so
+//     the stage is a compile-time constant,
+//   * the fragment reads are inline asm (invisible to the LDS-DMA alias rule); the block waits for its own reads
+//     (lgkmcnt(0)) and the stage being read was completed before the last barrier.
+struct __attribute__((aligned(16))) PixEntry { int h0, w0, xoff, dyoff; };
 
 template <int MT>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_rows(WgradArgs a) {
     constexpr int BMW = 32 * MT;
     constexpr int CA = BMW / 8;                      // valid dy chunks per pixel row
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TILE];     // [stage][A | B]
+    __shared__ PixEntry ptab[4][16];                                         // [wave][row group j*4 + lrow4]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -69,48 +79,60 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
 
     // LDS-DMA roles: wave-instruction j of wave w fills LDS rows (w*4+j)*4 .. +3; lane -> (row l>>4, phys chunk l&15)
     const int lrow4 = lane >> 4, phys = lane & 15;
-    // logical chunk per instruction parity (row & 7 = (j&1)*4 + lrow4)
-    int ac16[2], bcol_r[2], bcol_s[2], bcol_c[2];
-    bool avalid[2], bvalid[2];
+    constexpr unsigned OOB = 0x80000000u;            // buffer range check: reads zeros
+    constexpr int FAR = 1 << 24;                     // a row offset no valid input coordinate survives
+    int acol[2], bcol_r[2], bcol_s[2], btap[2];
+    bool avalid[2];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        int c16 = phys ^ (((par * 4 + lrow4) & 7) << 1);
-        ac16[par] = c16;
+    for (int par = 0; par < 2; ++par) {              // logical chunk per instruction parity (row & 7 = (j&1)*4 + lrow4)
+        const int c16 = phys ^ (((par * 4 + lrow4) & 7) << 1);
         avalid[par] = (c16 < CA) && (k0 + c16 * 8 < a.K);
-        int jcol = n0 + c16 * 8;
-        bvalid[par] = jcol < a.RSC;
-        int jj = bvalid[par] ? jcol : 0;
-        int rs = jj / a.C;
-        bcol_c[par] = jj - rs * a.C;
-        bcol_r[par] = rs / a.S;
-        bcol_s[par] = rs - bcol_r[par] * a.S;
+        acol[par] = (k0 + c16 * 8) * 2;
+        const int jcol = n0 + c16 * 8;
+        const bool bv = jcol < a.RSC;
+        const int jj = bv ? jcol : 0;
+        const int rs = jj / a.C;
+        const int c = jj - rs * a.C;
+        const int r = rs / a.S;
+        const int sx = rs - r * a.S;
+        bcol_r[par] = bv ? r : FAR;
+        bcol_s[par] = sx;
+        btap[par] = ((r * a.W + sx) * a.ldx + c) * 2;
     }
-
-    // buffer_load ... lds through SRDs: an out-of-range offset (padding, tail pixels, tail channels) reads zeros
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int HW = a.H * a.W;
+    // the pixel this lane decodes for its wave: table slot (lane & 15) = j*4 + lrow4 -> tile row (wave*4 + j)*4 + lrow4
+    const int slot = lane & 15;
+    const int myrow = (wave * 4 + (slot >> 2)) * 4 + (slot & 3);
+    PixEntry* const mytab = &ptab[wave][slot];
+    const PixEntry* const rdtab = &ptab[wave][lrow4];      // + j*4
 
-#define ISSUE_TILE(pix0, stage)                                                                                 \
+#define ISSUE_ROWS(pix0, stage)                                                                                 \
     {                                                                                                           \
+        {                                                                                                       \
+            const int pix = (pix0) + myrow;                                                                     \
+            const bool pv = pix < pix_end;                                                                      \
+            const uint32_t pp = pv ? (uint32_t)pix : 0u;                                                        \
+            const uint32_t n = fdiv(pp, a.fPQ);                                                                 \
+            const uint32_t rem = pp - n * a.fPQ.d;                                                              \
+            const uint32_t p = fdiv(rem, a.fQ);                                                                 \
+            const uint32_t q = rem - p * a.fQ.d;                                                                \
+            PixEntry e;                                                                                         \
+            e.h0 = pv ? (int)p * a.sh - a.ph : -FAR;                                                            \
+            e.w0 = (int)q * a.sw - a.pw;                                                                        \
+            e.xoff = (((int)n * a.H + ((int)p * a.sh - a.ph)) * a.W + e.w0) * a.ldx * 2;                        \
+            e.dyoff = pv ? (int)(pp * (uint32_t)a.ldy * 2u) : (int)OOB;                                         \
+            *mytab = e;       /* same-wave LDS traffic is ordered: no barrier between this store and the reads below */ \
+        }                                                                                                       \
         bf16_t* dstA = smem + (stage) * 2 * TILE;                                                               \
         bf16_t* dstB = dstA + TILE;                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
             const int par = j & 1;                                                                              \
-            const int row = (wave * 4 + j) * 4 + lrow4;                                                         \
-            const int pix = (pix0) + row;                                                                       \
-            const bool pv = pix < pix_end;                                                                      \
-            unsigned voA = (pv && avalid[par]) ? (unsigned)(pix * a.ldy + k0 + ac16[par] * 8) * 2u : OOB;       \
+            const PixEntry e = rdtab[j * 4];                                                                    \
+            const unsigned voA = avalid[par] ? (unsigned)e.dyoff + (unsigned)acol[par] : OOB;                   \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 4 * TW), 16, voA, 0, 0, 0); \
-            uint32_t pp = pv ? (uint32_t)pix : 0u;                                                              \
-            uint32_t n = fdiv(pp, a.fPQ);                                                                       \
-            uint32_t rem = pp - n * a.fPQ.d;                                                                    \
-            uint32_t p = fdiv(rem, a.fQ);                                                                       \
-            uint32_t q = rem - p * a.fQ.d;                                                                      \
-            int hi = (int)p * a.sh - a.ph + bcol_r[par], wi = (int)q * a.sw - a.pw + bcol_s[par];               \
-            bool v = pv && bvalid[par] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;         \
-            unsigned voB = v ? (unsigned)(((int)n * HW + hi * a.W + wi) * a.ldx + bcol_c[par]) * 2u : OOB;      \
+            const bool v = (unsigned)(e.h0 + bcol_r[par]) < (unsigned)a.H && (unsigned)(e.w0 + bcol_s[par]) < (unsigned)a.W; \
+            const unsigned voB = v ? (unsigned)(e.xoff + btap[par]) : OOB;                                      \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dstB + (wave * 4 + j) * 4 * TW), 16, voB, 0, 0, 0); \
         }                                                                                                       \
     }
@@ -122,41 +144,69 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (pix_end - pix_begin + BKP - 1) / BKP;
-    if (nsteps > 0) ISSUE_TILE(pix_begin, 0)
+    if (nsteps > 0) ISSUE_ROWS(pix_begin, 0)
     __syncthreads();
 
-    // transposing fragment reads: lane (g, q, p) addresses LDS row 4g+q (then +16), columns col0+4p..+3
+    // transposing fragment reads: lane (g, lq, lp) addresses LDS row 4g+lq (+32 per k half, +16 for the upper
+    // registers), columns col0+4lp..+3; (row & 7) -- the swizzle key -- is the same for all of them
     const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
     const int trow = 4 * g + lq;
-    for (int st = 0; st < nsteps; ++st) {
-        const int stage = st & 1;
-        if (st + 1 < nsteps) ISSUE_TILE(pix_begin + (st + 1) * BKP, stage ^ 1)
-        const bf16_t* tA = smem + stage * 2 * TILE;
-        const bf16_t* tB = tA + TILE;
+    const int swz = (trow & 7) << 1;
+    unsigned fa0[MT], fb0[4];                        // LDS byte addresses
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[MT], fb[4];
+    for (int mt = 0; mt < MT; ++mt) {
+        const int col = wm * (MT * 16) + mt * 16 + 4 * lp;
+        fa0[mt] = (unsigned)(size_t)(lptr_t)(smem + trow * TW + (((col >> 3) ^ swz) << 3) + (col & 7));
+    }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                int col = wm * (MT * 16) + mt * 16 + 4 * lp;
-                s16x4_t lo = tr_read(tr_addr(tA, kk * 32 + trow, col)), hi = tr_read(tr_addr(tA, kk * 32 + 16 + trow, col));
-                fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                int col = wn * 64 + nt * 16 + 4 * lp;
-                s16x4_t lo = tr_read(tr_addr(tB, kk * 32 + trow, col)), hi = tr_read(tr_addr(tB, kk * 32 + 16 + trow, col));
-                fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-        }
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = wn * 64 + nt * 16 + 4 * lp;
+        fb0[nt] = (unsigned)(size_t)(lptr_t)(smem + TILE + trow * TW + (((col >> 3) ^ swz) << 3) + (col & 7));
+    }
+
+#define TR_PAIR(lo, hi, addr, OFF)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
+                 : "=&v"(lo), "=&v"(hi)                                                                         \
+                 : "v"(addr), "n"(OFF), "n"((OFF) + 16 * TW * 2));
+#define MATH_ROWS(stage)                                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                          \
+        s16x4_t alo[MT], ahi[MT], blo[4], bhi[4];                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                     \
+            if (kk == 0) { TR_PAIR(alo[mt], ahi[mt], fa0[mt], (stage) * 2 * TILE * 2) }                         \
+            else { TR_PAIR(alo[mt], ahi[mt], fa0[mt], (stage) * 2 * TILE * 2 + 32 * TW * 2) }                   \
+        }                                                                                                       \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                      \
+            if (kk == 0) { TR_PAIR(blo[nt], bhi[nt], fb0[nt], (stage) * 2 * TILE * 2) }                         \
+            else { TR_PAIR(blo[nt], bhi[nt], fb0[nt], (stage) * 2 * TILE * 2 + 32 * TW * 2) }                   \
+        }                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        /* empty volatile asms keep their order after the wait and make every fragment (hence every MFMA) depend on it */ \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(alo[mt]), "+v"(ahi[mt]));      \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(blo[nt]), "+v"(bhi[nt]));       \
+        bf16x8_t fa[MT], fb[4];                                                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
+            fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[mt], ahi[mt], 0, 1, 2, 3, 4, 5, 6, 7)); \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                        \
+            fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[nt], bhi[nt], 0, 1, 2, 3, 4, 5, 6, 7)); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                       \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                    \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);    \
+    }
+
+    // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: the tile issued at the top of a step has landed
+    // (in every wave) before the next step reads it, and nobody still reads the stage the next issue overwrites
+    for (int st = 0; st < nsteps; st += 2) {
+        if (st + 1 < nsteps) ISSUE_ROWS(pix_begin + (st + 1) * BKP, 1)
+        MATH_ROWS(0)
+        __syncthreads();
+        if (st + 1 >= nsteps) break;
+        if (st + 2 < nsteps) ISSUE_ROWS(pix_begin + (st + 2) * BKP, 0)
+        MATH_ROWS(1)
         __syncthreads();
     }
-#undef ISSUE_TILE
+#undef ISSUE_ROWS
+#undef MATH_ROWS
+#undef TR_PAIR
 
     // slab store: lane holds rows k = 4g+j, column l&15
     float* out = a.slab + (size_t)split * a.K * a.RSC;
@@ -165,6 +215,171 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             int col = n0 + wn * 64 + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = k0 + wm * (MT * 16) + mt * 16 + 4 * g + j;
+                if (k < a.K && col < a.RSC) out[(size_t)k * a.RSC + col] = acc[mt][nt][j];
+            }
+        }
+}
+
+// ---------------------------------------------------------------- chunk-column tiles (K <= 64)
+// Same GEMM and the same transposing fragment reads, but the LDS image of a step is stored CHUNK-COLUMN major:
+// [column of 8 channels][64 pixels][16 B].  One LDS-DMA wave-instruction then fills one column -- lane = pixel -- so
+//   * a lane decodes ONE pixel (n,p,q) per step instead of four,
+//   * the (r,s,c) tap of a column is wave-uniform (SGPRs, set up once per block),
+//   * dy columns need no per-lane math at all (per-pixel offset + scalar column offset).
+// The leanest instruction stream, but a DMA instruction now touches 64 cache lines (16 B of each) instead of 8: it
+// wins where the tile has few MFMAs per step to hide instructions behind (K <= 64: the 149^2 / 147^2 stem layers, 1.1-1.5x)
+// and loses 15-30 % on the wider tiles (measured per layer, scripts/conv_layers.py).
+// Columns are 1152 B apart (1024 + 128 skew): the 32 lanes of a ds_read_b64_tr_b16 group then touch 32 distinct
+// 8-byte bank pairs (offsets (lp>>1)*128 + g*64 + lq*16 + (lp&1)*8 mod 256).
+constexpr int CSE = 576;    // column stride in bf16 elements (1152 B)
+
+// (a __device__ helper: with a run-time scalar offset the builtin is rejected -- silently, the kernel's host stub is
+// simply not emitted -- when it appears directly in a __global__ template that the host pass instantiates)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lptr_t dst, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+}
+
+// NTW: 16-column tiles per wave along (r,s,c): block tile = (32*MT) output channels x (32*NTW) columns
+template <int MT, int NTW>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_cols(WgradArgs a) {
+    constexpr int BMW = 32 * MT;
+    constexpr int CA = 4 * MT;                       // dy chunk columns of the block tile
+    constexpr int CB = 4 * NTW;                      // x chunk columns of the block tile
+    constexpr int BNC = 32 * NTW;
+    constexpr int STAGE = (CA + CB) * CSE;           // elements per pipeline stage
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / a.tiles;
+    const int tile = lin - split * a.tiles;
+    const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
+    const int k0 = mtile * BMW, n0 = ntile * BNC;
+    const int pix_begin = split * a.split_len;
+    const int pix_end = min(pix_begin + a.split_len, a.M);
+
+    // columns owned by this wave: dy columns ca = wave + 4i (i < MT), x columns cb = wave + 4i (i < NTW)
+    int soffA[MT];
+    bool colA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int kc = k0 + (wave + 4 * i) * 8;
+        colA[i] = kc < a.K;
+        soffA[i] = kc * 2;
+    }
+    int rB[NTW], sB[NTW], tapB[NTW];
+    bool colB[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int jcol = n0 + (wave + 4 * i) * 8;
+        colB[i] = jcol < a.RSC;
+        const int jj = colB[i] ? jcol : 0;
+        const int rs = jj / a.C;
+        const int c = jj - rs * a.C;
+        const int r = rs / a.S;
+        const int sx = rs - r * a.S;
+        rB[i] = __builtin_amdgcn_readfirstlane(r);
+        sB[i] = __builtin_amdgcn_readfirstlane(sx);
+        tapB[i] = __builtin_amdgcn_readfirstlane(((r * a.W + sx) * a.ldx + c) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const bool nopad = (a.ph | a.pw) == 0;           // every tap of every output pixel is inside the input
+
+#define ISSUE_COLS(pix0, stage)                                                                                 \
+    {                                                                                                           \
+        bf16_t* dst = smem + (stage) * STAGE;                                                                   \
+        const int pix = (pix0) + lane;                                                                          \
+        const bool pv = pix < pix_end;                                                                          \
+        const unsigned voA = pv ? (unsigned)(pix * a.ldy) * 2u : OOB;                                           \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+            if (colA[i])                                                                                        \
+                lds_dma16(rsA, (lptr_t)(dst + (wave + 4 * i) * CSE), voA, soffA[i]); \
+        const uint32_t pp = pv ? (uint32_t)pix : 0u;                                                            \
+        const uint32_t n = fdiv(pp, a.fPQ);                                                                     \
+        const uint32_t rem = pp - n * a.fPQ.d;                                                                  \
+        const uint32_t p = fdiv(rem, a.fQ);                                                                     \
+        const uint32_t q = rem - p * a.fQ.d;                                                                    \
+        const int h0 = (int)p * a.sh - a.ph, w0 = (int)q * a.sw - a.pw;                                         \
+        const int pixbase = (((int)n * a.H + h0) * a.W + w0) * a.ldx * 2;                                       \
+        _Pragma("unroll") for (int i = 0; i < NTW; ++i)                                                         \
+            if (colB[i]) {                                                                                      \
+                bool v = pv;                                                                                    \
+                if (!nopad) v = v && (unsigned)(h0 + rB[i]) < (unsigned)a.H && (unsigned)(w0 + sB[i]) < (unsigned)a.W; \
+                const unsigned vo = v ? (unsigned)(pixbase + tapB[i]) : OOB;                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst + (CA + wave + 4 * i) * CSE), 16, vo, 0, 0, 0); \
+            }                                                                                                   \
+    }
+
+    f32x4_t acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (pix_end - pix_begin + BKP - 1) / BKP;
+    if (nsteps > 0) ISSUE_COLS(pix_begin, 0)
+    __syncthreads();
+
+    // transposing fragment reads: lane (g, lq, lp) addresses pixel 4g+lq (then +16), channels col0+4lp..+3
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    const int lane_off = (lp >> 1) * CSE + (4 * g + lq) * 8 + (lp & 1) * 4;
+    const bf16_t* pA = smem + wm * (MT * 2) * CSE + lane_off;             // + mt*2*CSE + kk*256 (+128)
+    const bf16_t* pB = smem + (CA + wn * (NTW * 2)) * CSE + lane_off;             // + nt*2*CSE + kk*256 (+128)
+    for (int st = 0; st < nsteps; ++st) {
+        const int stage = st & 1;
+        if (st + 1 < nsteps) ISSUE_COLS(pix_begin + (st + 1) * BKP, stage ^ 1)
+        const bf16_t* tA = pA + stage * STAGE;
+        const bf16_t* tB = pB + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // inline-asm fragment reads: see conv_wgrad_rows (no compiler-inserted vmcnt(0) behind the LDS-DMA prefetch)
+            s16x4_t alo[MT], ahi[MT], blo[NTW], bhi[NTW];
+            const unsigned ua = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(tA + kk * 256);
+            const unsigned ub = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(tB + kk * 256);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                             : "=&v"(alo[mt]), "=&v"(ahi[mt]) : "v"(ua), "n"(mt * 2 * CSE * 2), "n"(mt * 2 * CSE * 2 + 256));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                             : "=&v"(blo[nt]), "=&v"(bhi[nt]) : "v"(ub), "n"(nt * 2 * CSE * 2), "n"(nt * 2 * CSE * 2 + 256));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(alo[mt]), "+v"(ahi[mt]));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) asm volatile("" : "+v"(blo[nt]), "+v"(bhi[nt]));
+            bf16x8_t fa[MT], fb[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[mt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[mt], ahi[mt], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                fb[nt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[nt], bhi[nt], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef ISSUE_COLS
+
+    // slab store: lane holds rows k = 4g+j, column l&15
+    float* out = a.slab + (size_t)split * a.K * a.RSC;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            int col = n0 + wn * (NTW * 16) + nt * 16 + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int k = k0 + wm * (MT * 16) + mt * 16 + 4 * g + j;
@@ -311,10 +526,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, float* dw
     }
 }
 
-int pick_mt(int K) {
+int pick_mt(int K, int maxmt) {
     int best = 1;
     long bestc = -1;
-    for (int mt = 1; mt <= 4; ++mt) {
+    for (int mt = 1; mt <= maxmt; ++mt) {
         int bm = 32 * mt;
         long c = (long)cdiv(K, bm) * (bm + 48);
         if (bestc < 0 || c < bestc || (c == bestc && mt > best)) { bestc = c; best = mt; }
@@ -322,19 +537,28 @@ int pick_mt(int K) {
     return best;
 }
 
-struct Plan { int mt, tilesM, tilesN, nsplit, split_len; size_t ws; };
+struct Plan { int mt, cols, tilesM, tilesN, nsplit, split_len; size_t ws; };
 
 Plan make_plan(const ifcbk_conv_desc* d) {
     Plan p;
     const int bkp = d->dtype == IFCBK_F32 ? F_BKP : BKP;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     int RSC = d->R * d->S * d->C;
-    p.mt = pick_mt(d->K);
+    p.mt = pick_mt(d->K, 4);
+    // bf16: chunk-column tiles for the narrow (K <= 64) layers, row-major tiles otherwise; IFCBK_WGRAD_COLS=0/1 forces one
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("IFCBK_WGRAD_COLS"); force = e ? atoi(e) : -1; }
+    p.cols = d->dtype == IFCBK_F32 ? 0 : (force >= 0 ? force : (p.mt <= 2));
     p.tilesM = cdiv(d->K, 32 * p.mt);
     p.tilesN = cdiv(RSC, BNW);
     int tiles = p.tilesM * p.tilesN;
     int64_t steps = (M + bkp - 1) / bkp;
-    int64_t ns = cdiv(1024, tiles);
+    // split count: fill the resident block slots (2 blocks per CU; 3 for the 46 KB chunk-column MT=1 kernel) for a whole
+    // number of rounds -- a few blocks over (cdiv) would cost a nearly empty extra round
+    static int rounds = -1;
+    if (rounds < 0) { const char* e = getenv("IFCBK_WGRAD_ROUNDS"); rounds = e ? atoi(e) : 1; }
+    const int slots = 256 * ((p.cols && p.mt == 1) ? 3 : 2);
+    int64_t ns = (int64_t)rounds * slots / tiles;
     int64_t maxsplit = steps / 8 > 0 ? steps / 8 : 1;
     if (ns > maxsplit) ns = maxsplit;
     if (ns < 1) ns = 1;
@@ -348,12 +572,18 @@ Plan make_plan(const ifcbk_conv_desc* d) {
 
 template <int MT>
 void launch(const WgradArgs& a, const Plan& p, hipStream_t st) {
-    hipLaunchKernelGGL(conv_wgrad_bf16<MT>, dim3(p.tilesM * p.tilesN * p.nsplit), dim3(NTHREADS), 0, st, a);
+    const dim3 grid(p.tilesM * p.tilesN * p.nsplit);
+    if (p.cols) hipLaunchKernelGGL((conv_wgrad_cols<MT, 4>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_rows<MT>, grid, dim3(NTHREADS), 0, st, a);
 }
 
 }  // namespace
 
-int ifcbk_conv_wgrad_mt(int K) { return pick_mt(K); }
+void ifcbk_conv_wgrad_shape(const ifcbk_conv_desc* d, int* mt, int* cols) {
+    Plan p = make_plan(d);
+    *mt = p.mt;
+    *cols = p.cols;
+}
 
 extern "C" size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc* d) { return make_plan(d).ws; }
 

@@ -184,7 +184,14 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %s>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, (d.stride_h == 2 || d.stride_w == 2) ? "true" : "false");
             break;
         }
-        case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: snprintf(name, cap, "conv_wgrad_bf16<%d>", ifcbk_conv_wgrad_mt(o->u.conv.K)); break;
+        case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: {
+            int mt = 0, cols = 0;
+            ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
+            if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
+            else if (cols) snprintf(name, cap, "conv_wgrad_cols<%d, 4>", mt);
+            else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
+            break;
+        }
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;

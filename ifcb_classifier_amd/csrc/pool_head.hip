@@ -412,20 +412,41 @@ __global__ __launch_bounds__(256) void gap_kernel(const T* x, int ldx, int HW, i
     }
 }
 
-// logits[n][j] = feat[n] . W[j] + b[j]; one block per sample, feat row in LDS, one wave per class
+// logits[n][j] = feat[n] . W[j] + b[j].  Block = FC_NB samples x one quarter of the classes: the FC_NB feature rows
+// sit in LDS, each wave owns a class and streams its weight row ONCE for all FC_NB samples (fixed summation order:
+// lane-strided partial sums, then a butterfly -- independent of the grid).
+constexpr int FC_NB = 8;
 __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* feat, const float* W, const float* b, float* logits,
-                                                     int C, int NC) {
-    extern __shared__ float sf[];
-    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int c = t; c < C; c += 256) sf[c] = feat[(size_t)n * C + c];
+                                                     int N, int C, int NC) {
+    extern __shared__ float sf[];                 // [FC_NB][C]
+    const int n0 = blockIdx.x * FC_NB, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = N - n0 < FC_NB ? N - n0 : FC_NB;
+    for (int i = t; i < FC_NB * C; i += 256) {
+        const int r = i / C;
+        sf[i] = r < nb ? feat[(size_t)n0 * C + i] : 0.f;
+    }
     __syncthreads();
-    for (int j = wave; j < NC; j += 4) {
+    for (int j = blockIdx.y * 4 + wave; j < NC; j += 4 * gridDim.y) {
         const float* w = W + (size_t)j * C;
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += sf[c] * w[c];
+        float s[FC_NB];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) logits[(size_t)n * NC + j] = s + b[j];
+        for (int r = 0; r < FC_NB; ++r) s[r] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float wv = w[c];
+#pragma unroll
+            for (int r = 0; r < FC_NB; ++r) s[r] += sf[r * C + c] * wv;
+        }
+#pragma unroll
+        for (int r = 0; r < FC_NB; ++r) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off);
+        }
+        if (lane == 0) {
+            const float bj = b[j];
+#pragma unroll
+            for (int r = 0; r < FC_NB; ++r)
+                if (r < nb) logits[(size_t)(n0 + r) * NC + j] = s[r] + bj;
+        }
     }
 }
 
@@ -680,12 +701,12 @@ extern "C" int ifcbk_head_fwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const vo
     if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: bad desc");
     const int e = dtype_chunk(d->dtype);
     if (d->C % e || d->ldx % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: channels must be multiples of %d", e);
-    if ((size_t)d->C * 4 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
+    if ((size_t)d->C * 4 * 8 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
     int64_t total = (int64_t)d->N * (d->C / e);
     if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(gap_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const float*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
     else hipLaunchKernelGGL(gap_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, ST, (const bf16_t*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
     IFCBK_LAUNCH_CHECK(ctx, "gap");
-    hipLaunchKernelGGL(fc_fwd_kernel, dim3(d->N), dim3(256), d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->C, d->NC);
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv(d->N, FC_NB), 4), dim3(256), (size_t)FC_NB * d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->N, d->C, d->NC);
     IFCBK_LAUNCH_CHECK(ctx, "fc_fwd");
     return 0;
 }
