@@ -36,6 +36,9 @@ struct ConvArgs {
     int accumulate;
     int PQ;
     int tilesN;
+    // MODE 2 (one parity class of a stride-2 dgrad): sub-filter taps inside the full flipped filter, scattered output
+    int wKg, wSfull, w_rbase, w_sbase;      // filter row length (elements), full S, first tap row / column (step 2)
+    int oH, oW, o_a, o_b;                   // dx dims and the class parity: output pixel (n,i,j) -> (n, 2i+o_a, 2j+o_b)
     fastdiv_t fPQ, fQ;
 };
 
@@ -70,6 +73,12 @@ template <> struct Mma<float> {
     __device__ static __forceinline__ void pack4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
 };
 
+// LDS-DMA with a run-time scalar offset (a __device__ helper: used directly in a __global__ template the host pass
+// silently drops the kernel's stub)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, lptr_t dst, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, soff, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -77,8 +86,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NT: 16-column tiles per wave in N (block N = 32*NT); WM: waves along M (block M = 64*WM, threads = 128*WM);
 // NSTAGE: LDS ring depth (NSTAGE-1 tiles of LDS-DMA in flight across the per-step barrier, counted vmcnt).
-template <class T, int NT, int WM, int NSTAGE, bool STRIDED>
+// MODE 0: forward / stride-1 dgrad.  MODE 1: dgrad with input dilation (any stride-2 filter; 3/4 of the taps multiply
+// zeros).  MODE 2: one parity class of a stride-2 dgrad as a dense stride-1 conv with the class's sub-filter.
+template <class T, int NT, int WM, int NSTAGE, int MODE>
 __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
+    constexpr bool STRIDED = MODE == 1;
     constexpr int ES = (int)sizeof(T);
     constexpr int CE = 16 / ES;                        // elements per 16-byte chunk
     constexpr int BK = 128 / ES;                       // k elements per tile step (128-byte rows)
@@ -147,6 +159,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
         }
         tapoff = (kr * a.W + ks) * a.ldx + kc;
     }
+    int wk = MODE == 2 ? ((a.w_rbase + 2 * kr) * a.wSfull + a.w_sbase + 2 * ks) * a.C + kc : 0;   // k index inside the FULL filter row
     unsigned woff[JB];
     bool gvalid[JB];
 #pragma unroll
@@ -154,44 +167,71 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
         int grp = j * NW + wave;
         gvalid[j] = grp < NT * 4;
         int n = n0 + grp * 8 + lrow8;
-        woff[j] = (gvalid[j] && n < a.K) ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
+        woff[j] = (gvalid[j] && n < a.K) ? (MODE == 2 ? (unsigned)(n * a.wKg) : (unsigned)(n * a.Kg + csrc * CE)) * (unsigned)ES : OOB;
     }
     const int nk = (a.Kg + BK - 1) / BK;
     const int hmask = (1 << a.ish) - 1, wmask = (1 << a.isw) - 1;
     const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
+    const int wrowskip = MODE == 2 ? (2 * a.wSfull - 2 * a.S) * a.C : 0;     // from the class's last tap column to the first of the next tap row
+
+    // 1x1 filter without padding (most layers of the inception / resnet graphs): the gather is a plain row read --
+    // per-lane offsets are constants and the k advance is a scalar (soffset): no per-step VALU address work at all
+    const bool plain = MODE == 0 && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    unsigned va[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) va[j] = bh[j] >= 0 ? (unsigned)(off0[j] + csrc * CE) * (unsigned)ES : OOB;
+    const bool ktail_ok = (nk - 1) * BK + csrc * CE < a.Kg;      // this lane's chunk of the LAST k step is inside the row
 
 #define ISSUE_TILE(kt, stage)                                                                              \
     {                                                                                                      \
         T* dstA = sStage + (stage) * STAGE;                                                                \
-        T* dstB = dstA + BM * BK;                                                                     \
-        const bool kvalid = kr < a.R;                                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
-            int hr = bh[j] + kr, wr = bw[j] + ks;                                                          \
-            unsigned voff;                                                                                 \
-            if (STRIDED) {                                                                                 \
-                bool v = kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0);       \
-                int hi = hr >> a.ish, wi = wr >> a.isw;                                                    \
-                v = v && hi < a.H && wi < a.W;                                                             \
-                voff = v ? (unsigned)(off0[j] + (hi * a.W + wi) * a.ldx + kc) * (unsigned)ES : OOB;                  \
-            } else {                                                                                       \
-                bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;           \
-                voff = v ? (unsigned)(off0[j] + tapoff) * (unsigned)ES : OOB;                                     \
+        T* dstB = dstA + BM * BK;                                                                          \
+        if (plain) {                                                                                       \
+            const bool cut = (kt) == nk - 1 && !ktail_ok;                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+                lds_dma16(rsA, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), cut ? OOB : va[j], (kt) * 128);   \
+        } else {                                                                                           \
+            const bool kvalid = kr < a.R;                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                int hr = bh[j] + kr, wr = bw[j] + ks;                                                      \
+                unsigned voff;                                                                             \
+                if (STRIDED) {                                                                             \
+                    bool v = kvalid && hr >= 0 && wr >= 0 && ((hr & hmask) == 0) && ((wr & wmask) == 0);   \
+                    int hi = hr >> a.ish, wi = wr >> a.isw;                                                \
+                    v = v && hi < a.H && wi < a.W;                                                         \
+                    voff = v ? (unsigned)(off0[j] + (hi * a.W + wi) * a.ldx + kc) * (unsigned)ES : OOB;    \
+                } else {                                                                                   \
+                    bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;       \
+                    voff = v ? (unsigned)(off0[j] + tapoff) * (unsigned)ES : OOB;                          \
+                }                                                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, voff, 0, 0, 0); \
             }                                                                                              \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (wave * 4 + j) * 8 * BK), 16, voff, 0, 0, 0); \
         }                                                                                                  \
-        const bool kv2 = ((kt) * BK + csrc * CE) < a.Kg;                                                    \
-        _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                                   \
-            unsigned voff = kv2 ? woff[j] + (unsigned)(kt) * 128u : OOB;                                    \
-            voff = woff[j] == OOB ? OOB : voff;                                                            \
-            T* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff, 0, 0, 0);                 \
+        if (MODE == 2) {                                                                                   \
+            const bool kv2 = ((kt) * BK + csrc * CE) < a.Kg;                                               \
+            _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                               \
+                unsigned voff = (kv2 && woff[j] != OOB) ? woff[j] + (unsigned)wk * (unsigned)ES : OOB;     \
+                T* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst, 16, voff, 0, 0, 0);             \
+            }                                                                                              \
+        } else {                                                                                           \
+            /* filter rows are k-contiguous: per-lane row offset + scalar k advance.  Chunks past Kg in the last step   \
+               read the head of the next row (or zeros past the buffer): harmless, the pixel operand is zero there */ \
+            _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                               \
+                T* dst = gvalid[j] ? dstB + (j * NW + wave) * 8 * BK : sDummy;                             \
+                lds_dma16(rsB, (lptr_t)dst, woff[j], (kt) * 128);                                          \
+            }                                                                                              \
         }                                                                                                  \
-        kc += BK;                                                                                          \
-        tapoff += BK;                                                                                      \
-        while (kc >= a.C) {                                                                                \
-            kc -= a.C;                                                                                     \
-            tapoff += a.ldx - a.C;                                                                         \
-            if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                                \
+        if (!plain) {                                                                                      \
+            kc += BK;                                                                                      \
+            tapoff += BK;                                                                                  \
+            if (MODE == 2) wk += BK;                                                                       \
+            while (kc >= a.C) {                                                                            \
+                kc -= a.C;                                                                                 \
+                tapoff += a.ldx - a.C;                                                                     \
+                if (MODE == 2) wk += a.C;                  /* next tap column: +2 taps, -C channels */     \
+                if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; if (MODE == 2) wk += wrowskip; } \
+            }                                                                                              \
         }                                                                                                  \
     }
 
@@ -284,7 +324,15 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                 if (m >= a.M) break;
                 float fv[CE];
                 Chunk<T>::load(sC + r * LDC + cc * CE, fv);          // values as they are stored (rounded for bf16)
-                T* dst = (T*)a.y + (size_t)m * a.ldy + nn;
+                size_t opix = (size_t)m;
+                if (MODE == 2) {
+                    const uint32_t on = fdiv((uint32_t)m, a.fPQ);
+                    const uint32_t orem = (uint32_t)m - on * a.fPQ.d;
+                    const uint32_t oi = fdiv(orem, a.fQ);
+                    const uint32_t oj = orem - oi * a.fQ.d;
+                    opix = ((size_t)on * a.oH + 2 * oi + a.o_a) * a.oW + 2 * oj + a.o_b;
+                }
+                T* dst = (T*)a.y + opix * a.ldy + nn;
                 if (a.part) {
 #pragma unroll
                     for (int j = 0; j < CE; ++j) {
@@ -384,8 +432,9 @@ template <class T, int NT, int WM, int NSTAGE>
 void launch(const ConvArgs& a, hipStream_t st) {
     int tilesM = cdiv(a.M, 64 * WM);
     dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
-    if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, false>), grid, block, 0, st, a);
+    if (a.wKg) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 2>), grid, block, 0, st, a);
+    else if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 0>), grid, block, 0, st, a);
 }
 
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
@@ -462,6 +511,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     a.P = d->P; a.Q = d->Q; a.ldy = d->ldy;
     a.ostr_h = d->stride_h; a.ostr_w = d->stride_w; a.base_h = -d->pad_h; a.base_w = -d->pad_w;
     a.ish = 0; a.isw = 0;
+    a.wKg = 0; a.wSfull = 0; a.w_rbase = 0; a.w_sbase = 0; a.oH = 0; a.oW = 0; a.o_a = 0; a.o_b = 0;
     a.M = d->N * d->P * d->Q; a.Kg = d->R * d->S * d->C; a.accumulate = 0; a.PQ = d->P * d->Q;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
     return run(ctx, a, d->dtype, (hipStream_t)stream);
@@ -480,9 +530,35 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
     a.K = d->C; a.R = d->R; a.S = d->S;
     a.P = d->H; a.Q = d->W; a.ldy = d->ldx;
     a.ostr_h = 1; a.ostr_w = 1;
+    a.wKg = 0; a.wSfull = 0; a.w_rbase = 0; a.w_sbase = 0; a.oH = 0; a.oW = 0; a.o_a = 0; a.o_b = 0;
+    a.accumulate = accumulate;
+    if (d->stride_h == 2 && d->stride_w == 2 && d->R >= 2 && d->S >= 2 && d->H >= 2 && d->W >= 2) {
+        // stride 2: dx pixels of parity class (pa, pb) only see the filter taps r = (pa+pad_h) mod 2 (+2, +4 ...), likewise s:
+        // four dense stride-1 convolutions over dy with sub-filters of the flipped filter (9 taps -> 4+2+2+1), each writing
+        // its own quarter of dx -- instead of one dilated gather in which 3 of 4 tap products are zeros.
+        for (int pa = 0; pa < 2; ++pa)
+            for (int pb = 0; pb < 2; ++pb) {
+                const int r0 = (pa + d->pad_h) & 1, s0 = (pb + d->pad_w) & 1;
+                const int nU = (d->R - r0 + 1) / 2, nV = (d->S - s0 + 1) / 2;
+                const int Hc = (d->H - pa + 1) / 2, Wc = (d->W - pb + 1) / 2;
+                ConvArgs c = a;
+                c.R = nU; c.S = nV;
+                c.P = Hc; c.Q = Wc;
+                c.base_h = (pa + d->pad_h - r0) / 2 - (nU - 1);
+                c.base_w = (pb + d->pad_w - s0) / 2 - (nV - 1);
+                c.ish = 0; c.isw = 0;
+                c.wKg = d->R * d->S * d->K; c.wSfull = d->S;
+                c.w_rbase = d->R - 1 - r0 - 2 * (nU - 1); c.w_sbase = d->S - 1 - s0 - 2 * (nV - 1);
+                c.oH = d->H; c.oW = d->W; c.o_a = pa; c.o_b = pb;
+                c.M = d->N * Hc * Wc; c.Kg = nU * nV * d->K; c.PQ = Hc * Wc;
+                c.fPQ = make_fastdiv(c.PQ); c.fQ = make_fastdiv(c.Q);
+                if (int e = run(ctx, c, d->dtype, (hipStream_t)stream)) return e;
+            }
+        return 0;
+    }
     a.base_h = -(d->R - 1 - d->pad_h); a.base_w = -(d->S - 1 - d->pad_w);
     a.ish = d->stride_h == 2 ? 1 : 0; a.isw = d->stride_w == 2 ? 1 : 0;
-    a.M = d->N * d->H * d->W; a.Kg = d->R * d->S * d->K; a.accumulate = accumulate; a.PQ = d->H * d->W;
+    a.M = d->N * d->H * d->W; a.Kg = d->R * d->S * d->K; a.PQ = d->H * d->W;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
     return run(ctx, a, d->dtype, (hipStream_t)stream);
 }

@@ -175,13 +175,17 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
-            snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, false>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
+            snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
             break;
         }
         case IFCBK_OP_CONV_DGRAD: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.H * d.W, d.C);
-            snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %s>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, (d.stride_h == 2 || d.stride_w == 2) ? "true" : "false");
+            {
+                const bool s2 = d.stride_h == 2 || d.stride_w == 2;
+                const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
+                snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, classes ? 2 : (s2 ? 1 : 0));
+            }
             break;
         }
         case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: {

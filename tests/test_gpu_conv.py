@@ -47,6 +47,10 @@ CASES = [
     (1, 64, 8, 8, 128, 1, 1, 2, 2, 0, 0),          # resnet downsample
     (1, 128, 5, 5, 768, 5, 5, 1, 1, 0, 0),         # aux conv1
     (5, 2048, 8, 8, 320, 1, 1, 1, 1, 0, 0),
+    (2, 64, 10, 10, 64, 3, 3, 2, 2, 1, 1),         # resnet 3x3 stride 2 pad 1 (even input): parity-class dgrad
+    (2, 32, 13, 11, 48, 3, 3, 2, 2, 1, 1),         # odd, non-square input
+    (1, 16, 8, 8, 16, 2, 2, 2, 2, 0, 0),           # 2x2 stride 2: one tap per class
+    (1, 24, 9, 9, 40, 5, 5, 2, 2, 2, 2),           # 5x5 stride 2: 9 / 6 / 6 / 4 taps
 ]
 
 
