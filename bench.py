@@ -115,6 +115,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-events', action='store_true', help='do not record per-launch HIP events in the timed region')
     ap.add_argument('--dump-ops', default=None, help='write the per-op timing table (JSON) here')
+    ap.add_argument('--train-only', action='store_true', help='skip the secondary RUN-mode (inference) measurement: '
+                    'the process then launches training kernels only, so a rocprofv3 --stats summary of it is comparable '
+                    'launch for launch with the per-kernel HIP-event times')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -180,13 +183,14 @@ def main():
         p = eng.forward_eval(B)
         eng.run(p.softmax)
 
-    for _ in range(2):
+    n_inf = 0 if args.train_only else args.steps
+    for _ in range(2 if n_inf else 0):
         infer_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     ti = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_inf):
         infer_step()
     torch.cuda.synchronize()
     if world > 1:
@@ -211,10 +215,11 @@ def main():
             'train_tflops': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3, 2),
             'mfma_frac_whole_step': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
             'final_loss': round(loss, 4),
-            'infer_images_per_s': round(world * B * args.steps / dti, 1),
-            'infer_ms_per_batch': round(1e3 * dti / args.steps, 3),
-            'infer_mfma_frac': round(world * B * args.steps / dti * 11.423e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
         }
+        if n_inf:
+            out.update({'infer_images_per_s': round(world * B * n_inf / dti, 1),
+                        'infer_ms_per_batch': round(1e3 * dti / n_inf, 3),
+                        'infer_mfma_frac': round(world * B * n_inf / dti * 11.423e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4)})
         if use_ev:
             n = pl.step.n
             ms = (C.c_float * n)()
@@ -239,7 +244,7 @@ def main():
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None
             try:        # HBM bytes per launch of the same kernel from the committed PMC passes (scripts/collect_traffic.py)
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))['kernels']
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1c_traffic.json')))['kernels']
                 traffic = round(tj[dom]['hbm_bytes_per_launch'])
             except Exception:
                 pass

@@ -394,6 +394,9 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
 }
 
 int pick_nt(int K, int maxnt = 6) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("IFCBK_CONV_NT"); force = e ? atoi(e) : 0; }
+    if (force > 0 && force <= maxnt) return force;
     int best = 1;
     long bestc = -1;
     for (int nt = 1; nt <= maxnt; ++nt) {

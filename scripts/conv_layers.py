@@ -23,12 +23,14 @@ LAYERS = {
 which = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] != 'all' else list(LAYERS)
 modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd', 'dgrad', 'wgrad']
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+NOVR = int(os.environ.get('CONV_LAYERS_N', '0'))
 ctx = _lib.Context(0)
 ctx.reserve(1 << 30)
 st = _lib.cur_stream()
 tot = {m: [0.0, 0.0] for m in modes}
 for name in which:
     N, Cc, H, W, K, R, S, sh, sw, ph, pw = LAYERS[name]
+    if NOVR: N = NOVR
     P = (H + 2 * ph - R) // sh + 1; Q = (W + 2 * pw - S) // sw + 1
     d = ConvDesc(N, H, W, Cc, Cc, K, R, S, sh, sw, ph, pw, P, Q, K, Cc, 0)
     x = torch.randn(N, H, W, Cc, device='cuda').bfloat16()
