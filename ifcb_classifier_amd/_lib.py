@@ -14,12 +14,13 @@ BF16, F32 = 0, 1
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
- OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG) = range(1, 23)
+ OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL) = range(1, 25)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
-            19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad'}
+            19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
+            24: 'bn_bwd_maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -85,6 +86,9 @@ _PROTOS = {
     'ifcbk_bn_apply': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'ifcbk_bn_bwd': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp,
                           _i, _vp, _vp, _vp]),
+    'ifcbk_bn_apply_maxpool': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'ifcbk_bn_bwd_maxpool': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i,
+                                  _vp]),
     'ifcbk_maxpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _vp]),
     'ifcbk_maxpool_bwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_avgpool_fwd': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp]),

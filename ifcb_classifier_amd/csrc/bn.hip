@@ -115,15 +115,56 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, int ldx, cons
     }
 }
 
+// ---------------------------------------------------------------- upstream gradient through a 3x3/stride-2 max pool
+// bn_bwd_maxpool: the activation of this BN feeds ONLY a max pool (inception Conv2d_2b / Conv2d_4a, the resnet stem),
+// so neither the activation nor its gradient is ever materialised: dy[n,h,w,c] is gathered from the pooled gradient
+// and the pool's u8 arg-max (an input pixel lies in at most 2x2 windows) -- the arithmetic of maxpool3x3s2_bwd_kernel.
+struct PoolGather {
+    const uint8_t* arg;
+    int H, W, P, Q, ph, pw, ldp, C;
+    fastdiv_t fHW, fW;
+};
+template <class T>
+__device__ __forceinline__ void pooled_dy(const PoolGather& g, const T* dp, uint32_t m, int c, float* fd) {
+    constexpr int E = Chunk<T>::N;
+    const uint32_t n = fdiv(m, g.fHW);
+    const uint32_t rem = m - n * g.fHW.d;
+    const int h = (int)fdiv(rem, g.fW);
+    const int w = (int)rem - h * g.W;
+    int plo = h + g.ph - 2; plo = plo <= 0 ? 0 : (plo + 1) >> 1;
+    int phi = (h + g.ph) >> 1; if (phi >= g.P) phi = g.P - 1;
+    int qlo = w + g.pw - 2; qlo = qlo <= 0 ? 0 : (qlo + 1) >> 1;
+    int qhi = (w + g.pw) >> 1; if (qhi >= g.Q) qhi = g.Q - 1;
+#pragma unroll
+    for (int j = 0; j < E; ++j) fd[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int p = plo + u, q = qlo + v;
+            if (p <= phi && q <= qhi) {
+                const int want = (h - (p * 2 - g.ph)) * 3 + (w - (q * 2 - g.pw));
+                const int64_t opix = (int64_t)(n * g.P + p) * g.Q + q;
+                int idx[E];
+                float f[E];
+                ArgPack<E>::load(g.arg + opix * g.C + c, idx);
+                Chunk<T>::load(dp + opix * g.ldp + c, f);
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    if (idx[j] == want) fd[j] += f[j];
+            }
+        }
+}
+
 // ---------------------------------------------------------------- backward
 // pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks x 32 rows in flight
 constexpr int BWD_ROWS = 1024;
 // MASK: 0 = no ReLU, 1 = ReLU mask read from y (residual case), 2 = ReLU mask recomputed as x*scale+shift > 0
 // (bit-identical to what bn_apply stored: same expression, the sign survives rounding) -- saves the y read
-template <class T, int MASK>
+template <class T, int MASK, bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
                                                              const float* mean, const float* invstd, const float* scale,
-                                                             const float* shift, float* part, int64_t M, int C) {
+                                                             const float* shift, float* part, int64_t M, int C, PoolGather pg) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;                    // channels per block
     __shared__ float red[4][2][CG];
@@ -147,7 +188,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx,
         for (int64_t m = mbeg + r0; m < mend; m += 32) {
             float fx[E], fy[E], fd[E];
             Chunk<T>::load(x + m * ldx + c, fx);
-            Chunk<T>::load(dy + m * lddy + c, fd);
+            if (POOLED) pooled_dy<T>(pg, dy, (uint32_t)m, c, fd);
+            else Chunk<T>::load(dy + m * lddy + c, fd);
             if (MASK == 1) Chunk<T>::load(y + m * ldy + c, fy);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -215,12 +257,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
 // pass 3: dx (and the residual branch gradient).  dx = A_c*dz + B_c*x + K_c with
 //   A = gamma*invstd,  B = -gamma*invstd^2*dgamma/M,  K = gamma*invstd*(mean*invstd*dgamma - dbeta)/M
 // staged per block in LDS together with bn_apply's (scale, shift) for the recomputed ReLU mask.
-template <class T, int MASK>
+template <class T, int MASK, bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
                                                          const float* gamma, const float* mean, const float* invstd,
                                                          const float* scale, const float* shift, const float* tmp,
                                                          T* dx, int lddx, T* dres, int lddres, int dres_acc, int64_t M,
-                                                         int C, float invM, fastdiv_t fcpr) {
+                                                         int C, float invM, fastdiv_t fcpr, PoolGather pg) {
     constexpr int E = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) float coef[];
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -244,7 +286,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* x, int ldx, con
         int c = ((int)i - (int)m * cpr) * E;
         float fx[E], fy[E], fd[E], o[E];
         Chunk<T>::load(x + (int64_t)m * ldx + c, fx);
-        Chunk<T>::load(dy + (int64_t)m * lddy + c, fd);
+        if (POOLED) pooled_dy<T>(pg, dy, m, c, fd);
+        else Chunk<T>::load(dy + (int64_t)m * lddy + c, fd);
         if (MASK == 1) Chunk<T>::load(y + (int64_t)m * ldy + c, fy);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -292,9 +335,11 @@ template <class T>
 int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy, int lddy,
           const float* gamma, const float* mean, const float* invstd, void* dx, int lddx, void* dres, int lddres,
           int dres_accumulate, float* dgamma, float* dbeta, int param_accumulate, const float* scale, const float* shift,
-          hipStream_t st) {
+          hipStream_t st, const PoolGather* pool = nullptr) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;
+    PoolGather pg = {};
+    if (pool) pg = *pool;
     const int C = d->C;
     if (C % E || d->ldx % E || lddy % E || lddx % E) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: channels must be multiples of %d", E);
     const int64_t M = d->M;
@@ -308,9 +353,13 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
     const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
     if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C);
+    if (pool) {
+        if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
+    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
@@ -320,9 +369,12 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     dim3 g3(cdiv(total, 256 * EW_ITER));
     const size_t shm = (size_t)5 * C * sizeof(float);
     const fastdiv_t fc = make_fastdiv(C / E);
-    if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 2>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
-    else hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 0>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc);
+    if (pool) {
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 2, true>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc, pg);
+        else hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 0, true>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc, pg);
+    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 2, false>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc, pg);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc, pg);
+    else hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 0, false>), g3, dim3(256), shm, st, xx, d->ldx, yy, d->ldy, dd, lddy, gamma, mean, invstd, scale, shift, (const float*)tmp, (T*)dx, lddx, (T*)dres, lddres, dres_accumulate, M, C, invM, fc, pg);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx");
     return 0;
 }
@@ -344,7 +396,7 @@ extern "C" int ifcbk_bn_finalize_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, cons
     if (part) {
         double M = (double)d->M;
         double unbias = d->M > 1 ? M / (M - 1.0) : 1.0;
-        if (mblocks > 512) {
+        if (mblocks > 1536) {
             // two-stage: 64-row chunks are pre-reduced by many blocks into the ctx workspace
             const int rpc = 64;
             int nchunk = cdiv(mblocks, rpc);
@@ -388,4 +440,111 @@ extern "C" int ifcbk_bn_bwd(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* 
         return bwd_t<bf16_t>(ctx, d, x, y, dy, lddy, gamma, mean, invstd, dx, lddx, dres, lddres, dres_accumulate, dgamma,
                              dbeta, param_accumulate, scale, shift, (hipStream_t)stream);
     IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: bad dtype");
+}
+
+// ---------------------------------------------------------------- BN apply (+ReLU) fused into a 3x3 max pool
+// y = maxpool3x3(act(x*scale+shift)); the activation is rounded to the storage type before the comparison, so values
+// and arg-max are those of bn_apply followed by maxpool_fwd -- without writing and re-reading the activation.
+namespace {
+struct ApplyPoolArgs {
+    int H, W, P, Q, cpr, ldx, ldy, sh, sw, ph, pw, relu;
+    uint32_t total;
+    fastdiv_t f_cpr, f_q, f_p;
+};
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* x, const float* scale, const float* shift, T* y,
+                                                               uint8_t* arg, ApplyPoolArgs a) {
+    constexpr int E = Chunk<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float coef[];
+    const int C = a.cpr * E;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        coef[c] = scale[c];
+        coef[C + c] = shift[c];
+    }
+    __syncthreads();
+    const uint32_t i = xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    if (i >= a.total) return;
+    const uint32_t pix = fdiv(i, a.f_cpr);
+    const int c = (int)(i - pix * a.cpr) * E;
+    const uint32_t t2 = fdiv(pix, a.f_q);
+    const int q = (int)(pix - t2 * a.Q);
+    const uint32_t n = fdiv(t2, a.f_p);
+    const int p = (int)(t2 - n * a.P);
+    const int h0 = p * a.sh - a.ph, w0 = q * a.sw - a.pw;
+    float sc[E], sf[E], best[E];
+    int bi[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) { sc[j] = coef[c + j]; sf[j] = coef[C + c + j]; best[j] = -INFINITY; bi[j] = 0; }
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int h = h0 + r;
+        if (h < 0 || h >= a.H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int w = w0 + s;
+            if (w < 0 || w >= a.W) continue;
+            float f[E];
+            Chunk<T>::load(x + ((int64_t)(n * a.H + h) * a.W + w) * a.ldx + c, f);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                float v = f[j] * sc[j] + sf[j];
+                if (a.relu) v = fmaxf(v, 0.f);
+                v = Chunk<T>::round(v);
+                if (first || v > best[j] || v != v) { best[j] = v; bi[j] = r * 3 + s; }
+            }
+            first = false;
+        }
+    }
+    Chunk<T>::store(y + (int64_t)pix * a.ldy + c, best);
+    if (arg) ArgPack<E>::store(arg + (int64_t)pix * C + c, bi);
+}
+
+int pooled_check(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const char* who) {
+    if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "%s: bad desc", who);
+    const int e = dtype_chunk(d->dtype);
+    if (d->C % e || d->ldx % e || d->ldy % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "%s: channels must be multiples of %d", who, e);
+    if (d->R != 3 || d->S != 3 || d->stride_h != 2 || d->stride_w != 2 || d->pad_h > 1 || d->pad_w > 1 || d->pad_h < 0 || d->pad_w < 0)
+        IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "%s: only 3x3 / stride 2 / pad <= 1 max pools are fused", who);
+    if ((int64_t)d->N * d->H * d->W * (d->C / e) >= (1ll << 31) - 256) IFCBK_FAIL(ctx, IFCBK_EINVAL, "%s: tensor too large", who);
+    return 0;
+}
+}  // namespace
+
+extern "C" int ifcbk_bn_apply_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, const float* scale,
+                                      const float* shift, int relu, void* y, uint8_t* argmax, void* stream) {
+    if (int e = pooled_check(ctx, d, "bn_apply_maxpool")) return e;
+    ApplyPoolArgs a;
+    a.H = d->H; a.W = d->W; a.P = d->P; a.Q = d->Q; a.ldx = d->ldx; a.ldy = d->ldy;
+    a.sh = 2; a.sw = 2; a.ph = d->pad_h; a.pw = d->pad_w; a.relu = relu;
+    a.cpr = d->C / dtype_chunk(d->dtype);
+    a.total = (uint32_t)((int64_t)d->N * d->P * d->Q * a.cpr);
+    a.f_cpr = make_fastdiv(a.cpr); a.f_q = make_fastdiv(d->Q); a.f_p = make_fastdiv(d->P);
+    if (a.total == 0) return IFCBK_OK;
+    const size_t shm = (size_t)2 * d->C * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(bn_apply_maxpool_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), shm, st, (const float*)x, scale, shift, (float*)y, argmax, a);
+    else hipLaunchKernelGGL(bn_apply_maxpool_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), shm, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, argmax, a);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_apply_maxpool");
+    return 0;
+}
+
+extern "C" int ifcbk_bn_bwd_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, const void* dpool,
+                                    const uint8_t* argmax, const float* gamma, const float* mean, const float* invstd,
+                                    const float* scale, const float* shift, int relu, void* dx, int lddx, float* dgamma,
+                                    float* dbeta, int param_accumulate, void* stream) {
+    if (int e = pooled_check(ctx, d, "bn_bwd_maxpool")) return e;
+    if (!argmax || !dpool) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: pooled gradient and arg-max required");
+    ifcbk_bn_desc b;
+    b.M = (int64_t)d->N * d->H * d->W; b.C = d->C; b.ldx = d->ldx; b.ldy = d->ldx; b.relu = relu; b.dtype = d->dtype;
+    b.eps = 0.f; b.momentum = 0.f;
+    PoolGather pg;
+    pg.arg = argmax; pg.H = d->H; pg.W = d->W; pg.P = d->P; pg.Q = d->Q; pg.ph = d->pad_h; pg.pw = d->pad_w;
+    pg.ldp = d->ldy; pg.C = d->C;
+    pg.fHW = make_fastdiv(d->H * d->W); pg.fW = make_fastdiv(d->W);
+    if (d->dtype == IFCBK_F32)
+        return bwd_t<float>(ctx, &b, x, nullptr, dpool, 0, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                            param_accumulate, scale, shift, (hipStream_t)stream, &pg);
+    return bwd_t<bf16_t>(ctx, &b, x, nullptr, dpool, 0, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                         param_accumulate, scale, shift, (hipStream_t)stream, &pg);
 }

@@ -70,11 +70,13 @@ template <> struct Chunk<bf16_t> {
     static constexpr int N = 8;
     __device__ static __forceinline__ void load(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
     __device__ static __forceinline__ void store(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }      // the value as it would be stored
 };
 template <> struct Chunk<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void load(const float* p, float* f) { *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p); }
     __device__ static __forceinline__ void store(float* p, const float* f) { *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f); }
+    __device__ static __forceinline__ float round(float v) { return v; }
 };
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
 __device__ __forceinline__ float to_f32(float v) { return v; }
@@ -100,6 +102,32 @@ static inline fastdiv_t make_fastdiv(uint32_t d) {
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const fastdiv_t& f) {
     return (__umulhi(n, f.mul) + n) >> f.shift;
 }
+
+// u8 arg-max of a max pool, one byte per channel, packed per 16-byte activation chunk (8 bf16 / 4 fp32 channels)
+template <int E> struct ArgPack;
+template <> struct ArgPack<8> {
+    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
+        uint2 v;
+        v.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        v.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bi[j] = ((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xff;
+    }
+};
+template <> struct ArgPack<4> {
+    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
+        *reinterpret_cast<uint32_t*>(p) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
+        uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bi[j] = (v >> (8 * j)) & 0xff;
+    }
+};
 
 int ifcbk_conv_fwd_nt(int K);
 int ifcbk_conv_fwd_wm(int M, int K);

@@ -83,6 +83,12 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_bn_bwd(c, &o->u.bn, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
                                 (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc, (float*)p[8], (float*)p[9],
                                 pacc, (const float*)p[10], (const float*)p[11], st);
+        case IFCBK_OP_BN_APPLY_MAXPOOL:
+            return ifcbk_bn_apply_maxpool(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (int)o->i[0], p[3], (uint8_t*)p[4], st);
+        case IFCBK_OP_BN_BWD_MAXPOOL:
+            return ifcbk_bn_bwd_maxpool(c, &o->u.pool, p[0], p[1], (const uint8_t*)p[2], (const float*)p[3], (const float*)p[4],
+                                        (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[0], p[8], (int)o->i[1],
+                                        (float*)p[9], (float*)p[10], pacc, st);
         case IFCBK_OP_MAXPOOL_FWD: return ifcbk_maxpool_fwd(c, &o->u.pool, p[0], p[1], (uint8_t*)p[2], st);
         case IFCBK_OP_MAXPOOL_BWD: return ifcbk_maxpool_bwd(c, &o->u.pool, p[0], (const uint8_t*)p[1], p[2], acc, st);
         case IFCBK_OP_AVGPOOL_FWD: return ifcbk_avgpool_fwd(c, &o->u.pool, p[0], p[1], st);
@@ -198,6 +204,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         }
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
+        case IFCBK_OP_BN_APPLY_MAXPOOL: snprintf(name, cap, "bn_apply_maxpool_kernel"); break;
+        case IFCBK_OP_BN_BWD_MAXPOOL: snprintf(name, cap, "bn_bwd(maxpool)"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;
         case IFCBK_OP_MAXPOOL_FWD: snprintf(name, cap, "maxpool_fwd_kernel"); break;
         case IFCBK_OP_MAXPOOL_BWD: snprintf(name, cap, "maxpool_bwd_kernel"); break;
@@ -226,6 +234,16 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
         }
         case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;
         case IFCBK_OP_BN_BWD: by = (double)o->u.bn.M * o->u.bn.C * (2.0 * (o->u.bn.relu ? 6 : 4) + 2 + (o->p[7] ? 2 : 0)); break;
+        case IFCBK_OP_BN_APPLY_MAXPOOL: {
+            const ifcbk_pool_desc& d = o->u.pool;
+            by = ((double)d.N * d.H * d.W * 2 + (double)d.N * d.P * d.Q * 3) * d.C;      // x in; pooled y + u8 arg-max out
+            break;
+        }
+        case IFCBK_OP_BN_BWD_MAXPOOL: {
+            const ifcbk_pool_desc& d = o->u.pool;
+            by = ((double)d.N * d.H * d.W * (2 * 2 + 2) + (double)d.N * d.P * d.Q * 3 * 2) * d.C;   // x twice, dx once; pooled grad + arg-max twice
+            break;
+        }
         case IFCBK_OP_MAXPOOL_FWD: case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_MAXPOOL_BWD: case IFCBK_OP_AVGPOOL_BWD: {
             const ifcbk_pool_desc& d = o->u.pool;
             by = ((double)d.N * d.H * d.W + (double)d.N * d.P * d.Q) * d.C * 2;

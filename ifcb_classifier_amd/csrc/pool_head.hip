@@ -21,31 +21,6 @@ PoolArgs make_pool(const ifcbk_pool_desc* d, bool bwd) {
     return a;
 }
 
-template <int E> struct ArgPack;
-template <> struct ArgPack<8> {
-    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
-        uint2 v;
-        v.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-        v.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
-        *reinterpret_cast<uint2*>(p) = v;
-    }
-    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
-        uint2 v = *reinterpret_cast<const uint2*>(p);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bi[j] = ((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xff;
-    }
-};
-template <> struct ArgPack<4> {
-    __device__ static __forceinline__ void store(uint8_t* p, const int* bi) {
-        *reinterpret_cast<uint32_t*>(p) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-    }
-    __device__ static __forceinline__ void load(const uint8_t* p, int* bi) {
-        uint32_t v = *reinterpret_cast<const uint32_t*>(p);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bi[j] = (v >> (8 * j)) & 0xff;
-    }
-};
-
 template <class T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, uint8_t* arg, PoolArgs a) {
     constexpr int E = Chunk<T>::N;

@@ -340,6 +340,25 @@ class Engine:
             written.add(buf.id)
             return a
 
+        # conv -> BN -> ReLU whose activation feeds ONLY a 3x3/stride-2 max pool (inception Conv2d_2b / Conv2d_4a, the
+        # resnet stem): in training the activation and its gradient are never materialised (bn_apply_maxpool / bn_bwd_maxpool)
+        readers = {}
+        for m in net.nodes:
+            for v in ((m.x, getattr(m, 'residual', None)) if m.kind == 'conv' else (m.x,)):
+                if v is not None:
+                    readers.setdefault(v.buf.id, []).append(m)
+        fused_pool = {}       # conv node -> (pool node, its index);  and the set of fused pool nodes
+        if os.environ.get('IFCBK_FUSE_POOL', '1') != '0':
+            for kk, m in enumerate(net.nodes):
+                if (m.kind == 'max' and m.R == 3 and m.S == 3 and m.sh == 2 and m.sw == 2 and m.ph <= 1 and m.pw <= 1
+                        and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1):
+                    prod = [c for c in net.nodes if c.kind == 'conv' and c.y.buf.id == m.x.buf.id]
+                    if (len(prod) == 1 and prod[0].y.is_full and prod[0].relu and prod[0].residual is None
+                            and prod[0].group is None and bool(prod[0].aux) == bool(m.aux)):
+                        fused_pool[prod[0]] = (m, kk)
+        fused_pool_nodes = {v[0] for v in fused_pool.values()}
+        self.fused_pool = fused_pool
+
         bwd_groups = []
         for k, n in enumerate(net.nodes):
             grp = OpList()
@@ -397,6 +416,14 @@ class Engine:
                                    _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
                                    self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3)),
                                 i=(mb,), bn=bnd)
+                    if train and n in fused_pool:
+                        pn, pk = fused_pool[n]
+                        ppd = PoolDesc(N, pn.x.H, pn.x.W, pn.x.C, ldraw, 3, 3, 2, 2, pn.ph, pn.pw, pn.P, pn.Q, pn.y.buf.C,
+                                       self.cdtype)
+                        lst.add(_lib.OP_BN_APPLY_MAXPOOL, n.name + '+' + pn.name,
+                                p=(raw, self._stat(n, 2), self._stat(n, 3), self._aptr(pn.y), _vp(self.argmax[pk])),
+                                i=(1,), pool=ppd)
+                        continue
                     lst.add(_lib.OP_BN_APPLY, n.name,
                             p=(raw, self._stat(n, 2 if train else 4), self._stat(n, 3 if train else 5), res, self._aptr(n.y)),
                             i=(ldr,), bn=bnd)
@@ -418,6 +445,8 @@ class Engine:
                     if n.aux and not train:
                         continue
                     if n.kind == 'max':
+                        if train and n in fused_pool_nodes:
+                            continue              # done by the producing conv's bn_apply_maxpool
                         lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd)
                     else:
                         lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd)
@@ -447,6 +476,8 @@ class Engine:
             elif g[0] == 'pool':
                 _, n, pd, k = g
                 assert n.x.is_full
+                if n in fused_pool_nodes:
+                    continue                      # gathered inside the producer's bn_bwd_maxpool
                 acc = acc_flag(n.x.buf)
                 if n.kind == 'max':
                     bwd.add(_lib.OP_MAXPOOL_BWD, n.name, p=(self._aptr(n.y, True), _vp(self.argmax[k]), self._aptr(n.x, True)), flags=acc, pool=pd)
@@ -462,11 +493,20 @@ class Engine:
                     dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
                 grp = n.group
                 rawp, _ld = self._raw_ptr(n)
-                bwd.add(_lib.OP_BN_BWD, n.name,
-                        p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
-                           self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
-                           self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
-                        i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd)
+                if n in fused_pool:
+                    pn, pk = fused_pool[n]
+                    ppd = PoolDesc(N, pn.x.H, pn.x.W, pn.x.C, _ld, 3, 3, 2, 2, pn.ph, pn.pw, pn.P, pn.Q, pn.y.buf.C, self.cdtype)
+                    bwd.add(_lib.OP_BN_BWD_MAXPOOL, n.name + '+' + pn.name,
+                            p=(rawp, self._aptr(pn.y, True), _vp(self.argmax[pk]), self._pptr(bkey + '.weight'),
+                               self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3), draw,
+                               self._pptr(bkey + '.weight', 'G'), self._pptr(bkey + '.bias', 'G')),
+                            i=(1, n.K), pool=ppd)
+                else:
+                    bwd.add(_lib.OP_BN_BWD, n.name,
+                            p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
+                               self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
+                               self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
+                            i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd)
                 if grp is not None:
                     # fused siblings: every member's d(raw) lands in its slice of the merged scratch; the member that
                     # comes FIRST in forward order is the last one here and launches the single wgrad + dgrad
@@ -565,6 +605,8 @@ class Engine:
             return [(o.p[2 + k] - base) // 4 for k in range(4) if o.i[k] > 0]
         if o.kind == _lib.OP_BN_BWD:
             return [(o.p[8] - base) // 4, (o.p[9] - base) // 4]
+        if o.kind == _lib.OP_BN_BWD_MAXPOOL:
+            return [(o.p[9] - base) // 4, (o.p[10] - base) // 4]
         if o.kind == _lib.OP_HEAD_BWD:
             return [(o.p[4] - base) // 4, (o.p[5] - base) // 4]
         return []

@@ -210,6 +210,21 @@ int ifcbk_nchw_to_nhwc(ifcbk_ctx*, const float* x, int N, int C, int H, int W, i
 int ifcbk_nhwc_to_nchw_f32(ifcbk_ctx*, const void* x, int N, int C, int H, int W, int ldx, int dtype,
                            float* y, void* stream);
 
+/* BN apply (+ReLU) fused into the 3x3 / stride-2 max pool that is the activation's only consumer (inception
+ * Conv2d_2b -> maxpool1, Conv2d_4a -> maxpool2; the resnet stem): y = maxpool(act(x*scale+shift)), values and
+ * arg-max exactly those of ifcbk_bn_apply followed by ifcbk_maxpool_fwd, the activation is never written.
+ * d: N,H,W,C of the conv output x (ldx = its pixel stride), P,Q,ldy of the pooled output, R=S=3, stride 2.
+ * Replaces [TV] `F.relu(bn(conv(x)))` + `F.max_pool2d(x, 3, 2)` (inception.py forward; reference call site
+ * neuston_models.py:66-68).                                                                             */
+int ifcbk_bn_apply_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, const float* scale,
+                           const float* shift, int relu, void* y, uint8_t* argmax, void* stream);
+/* ... and its backward: BN backward whose upstream gradient is maxpool_bwd(dpool, argmax), gathered on the fly
+ * (neither the activation nor its gradient exists in memory).  dx: gradient of the conv output (ld lddx). */
+int ifcbk_bn_bwd_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, const void* dpool,
+                         const uint8_t* argmax, const float* gamma, const float* mean, const float* invstd,
+                         const float* scale, const float* shift, int relu, void* dx, int lddx, float* dgamma,
+                         float* dbeta, int param_accumulate, void* stream);
+
 /* ------------------------------------------------------------------ program runner
  * One call launches a whole forward / backward / update list: the host builds the op table once
  * (static graph), so the per-step host cost is one FFI crossing.                                     */
@@ -219,7 +234,7 @@ enum {
     IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
-    IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG
+    IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL
 };
 typedef struct {
     int32_t kind;

@@ -34,6 +34,8 @@ def check_plan(hip, N, mask=None, verbose=False):
             print('%-8s %-34s %.3e' % (k, name, e))
         worst[k] = max(worst[k], e)
 
+    fused = getattr(eng, 'fused_pool', {})            # conv node -> (max-pool node, index): activation never materialised
+    fused_y = {}                                      # pool node -> the oracle's activation of the HIP raw output
     for k, n in enumerate(net.nodes):
         if n.kind == 'conv':
             x = act(n.x)
@@ -46,12 +48,19 @@ def check_plan(hip, N, mask=None, verbose=False):
             upd('raw', rel(raw_h, O.conv_raw(x, w, stride, pad)), n.name)
             res = act(n.residual) if n.residual is not None else None
             y_ref, mean, var = O.bn_act_fwd(raw_h, gamma, beta, n.eps, n.relu, res)
-            upd('y', rel(act(n.y), y_ref), n.name)
+            if n in fused:
+                pn = fused[n][0]
+                fused_y[pn] = y_ref
+                y_h = y_ref
+                gy = O.pool_bwd('max', y_ref, (pn.R, pn.S), (pn.sh, pn.sw), (pn.ph, pn.pw), grd(pn.y))
+            else:
+                y_h = act(n.y)
+                gy = grd(n.y)
+                upd('y', rel(y_h, y_ref), n.name)
             st_mean = eng.stats[n.st_off:n.st_off + n.K].cpu()
             st_is = eng.stats[n.st_off + n.st_ld:n.st_off + n.st_ld + n.K].cpu()
             upd('stats', max(rel(st_mean, mean), rel(st_is, 1.0 / torch.sqrt(var + n.eps))), n.name)
-            gy = grd(n.y)
-            d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy, y_for_mask=act(n.y))
+            d_raw, dg, db, dres = O.bn_act_bwd(raw_h, gamma, beta, n.eps, n.relu, res, gy, y_for_mask=y_h)
             upd('dgamma', rel(G[n.bn_key + '.weight'], dg), n.name)
             upd('dbeta', rel(G[n.bn_key + '.bias'], db), n.name)
             need_dx = not n.x.buf.is_input
@@ -62,9 +71,10 @@ def check_plan(hip, N, mask=None, verbose=False):
             if dres is not None:
                 add_expected(n.residual, dres)
         elif n.kind in ('max', 'avg'):
-            x = act(n.x)
+            x = fused_y[n] if n in fused_y else act(n.x)
             upd('pool', rel(act(n.y), O.pool_fwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw))), n.name)
-            add_expected(n.x, O.pool_bwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw), grd(n.y)))
+            if n not in fused_y:
+                add_expected(n.x, O.pool_bwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw), grd(n.y)))
         elif n.kind == 'head':
             x = act(n.x)
             W, b = P[n.key + '.weight'], P[n.key + '.bias']

@@ -174,6 +174,62 @@ def test_bn_fwd_bwd_vs_oracle(ctx, N, Cc, H, W, ld, relu, res):
         assert (nchw(dresd) - _bf(dres)).abs().max().item() <= 1e-2 * dres.abs().max().item()
 
 
+@pytest.mark.parametrize('N,Cc,H,W,pad,dtype', [(3, 64, 21, 21, 0, 0), (2, 192, 15, 13, 0, 0), (2, 64, 16, 16, 1, 0),
+                                               (2, 32, 9, 12, 1, 1)])
+def test_bn_maxpool_fused_equals_unfused(ctx, N, Cc, H, W, pad, dtype):
+    """ifcbk_bn_apply_maxpool == bn_apply -> maxpool_fwd bit for bit (values and arg-max), and ifcbk_bn_bwd_maxpool ==
+    maxpool_bwd -> bn_bwd: bit for bit in fp32 storage; in bf16 storage the unfused path rounds the (never stored here)
+    activation gradient -- a sum of up to four pooled gradients -- to bf16, the fused path keeps it in fp32; [TV] inception.py
+    `F.max_pool2d(relu(bn(conv(x))), 3, 2)`, reference call site neuston_models.py:66-68."""
+    from ifcb_classifier_amd import _lib
+    g = torch.Generator().manual_seed(N * 1000 + Cc + H)
+    tdt = torch.float32 if dtype else torch.bfloat16
+    P, Q = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    raw = (torch.randn(N, H, W, Cc, generator=g) * 2 + 0.3).to(tdt).cuda()
+    scale = (torch.randn(Cc, generator=g) * 0.7).cuda()            # negative scales too: affine before the max, always
+    shift = (torch.randn(Cc, generator=g) * 0.3).cuda()
+    gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    mean = torch.randn(Cc, generator=g).cuda() * 0.2
+    invstd = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    dpool = torch.randn(N, P, Q, Cc, generator=g).to(tdt).cuda()
+    st = _lib.cur_stream()
+    M = N * H * W
+    bd = _lib.BnDesc(M, Cc, Cc, Cc, 1, dtype, 1e-3, 0.1)
+    pd = _lib.PoolDesc(N, H, W, Cc, Cc, 3, 3, 2, 2, pad, pad, P, Q, Cc, dtype)
+    ctx.reserve(1 << 24)
+    # ---- unfused
+    y = torch.empty(N, H, W, Cc, dtype=tdt, device='cuda')
+    yp = torch.empty(N, P, Q, Cc, dtype=tdt, device='cuda')
+    arg = torch.empty(N, P, Q, Cc, dtype=torch.uint8, device='cuda')
+    ctx.call('ifcbk_bn_apply', C.byref(bd), _lib.ptr(raw), _lib.ptr(scale), _lib.ptr(shift), None, 0, _lib.ptr(y), st)
+    ctx.call('ifcbk_maxpool_fwd', C.byref(pd), _lib.ptr(y), _lib.ptr(yp), _lib.ptr(arg), st)
+    dy = torch.empty_like(y)
+    ctx.call('ifcbk_maxpool_bwd', C.byref(pd), _lib.ptr(dpool), _lib.ptr(arg), _lib.ptr(dy), 0, st)
+    dx = torch.empty_like(y)
+    dg, db = torch.zeros(Cc).cuda(), torch.zeros(Cc).cuda()
+    ctx.call('ifcbk_bn_bwd', C.byref(bd), _lib.ptr(raw), _lib.ptr(y), _lib.ptr(dy), Cc, _lib.ptr(gamma), _lib.ptr(mean),
+             _lib.ptr(invstd), _lib.ptr(dx), Cc, None, 0, 0, _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(scale), _lib.ptr(shift), st)
+    # ---- fused
+    yp2 = torch.empty_like(yp)
+    arg2 = torch.empty_like(arg)
+    ctx.call('ifcbk_bn_apply_maxpool', C.byref(pd), _lib.ptr(raw), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(yp2),
+             _lib.ptr(arg2), st)
+    dx2 = torch.empty_like(dx)
+    dg2, db2 = torch.zeros(Cc).cuda(), torch.zeros(Cc).cuda()
+    ctx.call('ifcbk_bn_bwd_maxpool', C.byref(pd), _lib.ptr(raw), _lib.ptr(dpool), _lib.ptr(arg2), _lib.ptr(gamma),
+             _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(dx2), Cc, _lib.ptr(dg2),
+             _lib.ptr(db2), 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(yp, yp2)
+    assert torch.equal(arg, arg2)
+    if dtype:
+        assert torch.equal(dg, dg2) and torch.equal(db, db2)
+        assert torch.equal(dx, dx2)
+    else:
+        for a, b in ((dg, dg2), (db, db2), (dx.float(), dx2.float())):
+            assert (a - b).abs().max().item() <= 1e-2 * a.abs().max().item()
+
+
 def test_bn_eval_scale_shift(ctx):
     from ifcb_classifier_amd import _lib
     Cc = 40
