@@ -6,15 +6,21 @@
 #include <string>
 #include "../../include/ifcbk.h"
 
+constexpr int IFCBK_MAX_LANES = 4;
 struct ifcbk_ctx {
     int device;
-    void* ws;            // workspace arena (split-K slabs, resize tables)
-    size_t ws_bytes;
+    void* ws;            // workspace arena of the lane that is launching (split-K slabs, BN partials, resize tables)
+    size_t ws_bytes;     // per lane
+    void* ws_base;       // IFCBK_MAX_LANES arenas of ws_bytes each
+    hipStream_t lane_st[IFCBK_MAX_LANES];   // lanes 1.. of ifcbk_run_program (lane 0 is the caller's stream)
+    hipEvent_t xev[64];  // cross-lane ordering events, used round-robin
+    int n_xev, xev_next;
     void* zeros;         // 4 KiB of zeros: source address of padded / out-of-range LDS-DMA chunks
     hipEvent_t* ev;      // profiling events for ifcbk_run_program
     int n_ev;
-    hipEvent_t* slot_ev[256];   // ifcbk_run_program_ev
+    hipEvent_t* slot_ev[256];   // ifcbk_run_program_ev: (start, stop) per op
     int slot_n[256];
+    unsigned char* slot_rec[256];   // which ops of the slot's last run were bracketed (flags bit 7)
     char err[512];
 };
 

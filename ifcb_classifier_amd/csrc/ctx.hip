@@ -24,13 +24,17 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
 
 extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     if (!c) return IFCBK_OK;
-    if (c->ws) (void)hipFree(c->ws);
+    if (c->ws_base) (void)hipFree(c->ws_base);
     if (c->zeros) (void)hipFree(c->zeros);
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+        if (c->lane_st[l]) (void)hipStreamDestroy(c->lane_st[l]);
+    for (int i = 0; i < c->n_xev; ++i) (void)hipEventDestroy(c->xev[i]);
     for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     free(c->ev);
     for (int s = 0; s < 256; ++s) {
         for (int i = 0; i < c->slot_n[s]; ++i) (void)hipEventDestroy(c->slot_ev[s][i]);
         free(c->slot_ev[s]);
+        free(c->slot_rec[s]);
     }
     free(c);
     return IFCBK_OK;
@@ -41,11 +45,12 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
     if (bytes <= c->ws_bytes) return IFCBK_OK;
     IFCBK_HIP(c, hipSetDevice(c->device));
     IFCBK_HIP(c, hipDeviceSynchronize());
-    if (c->ws) IFCBK_HIP(c, hipFree(c->ws));
-    c->ws = nullptr;
+    if (c->ws_base) IFCBK_HIP(c, hipFree(c->ws_base));
+    c->ws = c->ws_base = nullptr;
     c->ws_bytes = 0;
     bytes = (bytes + 255) & ~(size_t)255;
-    IFCBK_HIP(c, hipMalloc(&c->ws, bytes));
+    IFCBK_HIP(c, hipMalloc(&c->ws_base, bytes * IFCBK_MAX_LANES));     // one arena per program lane
+    c->ws = c->ws_base;
     c->ws_bytes = bytes;
     return IFCBK_OK;
 }
@@ -119,58 +124,103 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
     }
 }
 
+// ---------------------------------------------------------------- program runner with lanes
+// An op carries its lane (flags bits 8-9) and a wait mask (bits 12-15): "before this op, make my lane wait for
+// everything queued so far on those lanes".  Lane 0 is the caller's stream; lanes 1-3 are ctx-owned streams.  The host
+// (engine.py) computes lanes and masks from the static data flow, so independent branches of the graph overlap --
+// the tail of one kernel (a 578-block grid on 512 resident slots runs a nearly empty second round) is filled by the
+// next branch's kernel.  Every lane joins lane 0 at the end of the program: to the caller it is one stream-ordered call.
+static inline int op_lane(const ifcbk_op* o) { return (o->flags >> 8) & 3; }
+static inline int op_wait(const ifcbk_op* o) { return (o->flags >> 12) & 15; }
+
+static int lane_order(ifcbk_ctx* c, hipStream_t waiter, hipStream_t waited) {
+    if (c->n_xev < 64) {
+        for (int i = c->n_xev; i < 64; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
+        c->n_xev = 64;
+    }
+    hipEvent_t ev = c->xev[c->xev_next];
+    c->xev_next = (c->xev_next + 1) & 63;
+    IFCBK_HIP(c, hipEventRecord(ev, waited));
+    IFCBK_HIP(c, hipStreamWaitEvent(waiter, ev, 0));
+    return IFCBK_OK;
+}
+
+// ev: null, or 2n events (start, stop of every op, recorded on the op's own lane)
+static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, hipEvent_t* ev, unsigned char* rec = nullptr) {
+    hipStream_t st[IFCBK_MAX_LANES] = {s0, nullptr, nullptr, nullptr};
+    int used = 1;
+    for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+        if (used >> l & 1) {
+            if (!c->lane_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
+            st[l] = c->lane_st[l];
+            if (int e = lane_order(c, st[l], s0)) return e;                 // fork: the lane starts after the caller's prior work
+        }
+    int rc = IFCBK_OK;
+    for (int i = 0; i < n && !rc; ++i) {
+        const int L = op_lane(&ops[i]);
+        const int wm = op_wait(&ops[i]) & used & ~(1 << L);
+        for (int j = 0; j < IFCBK_MAX_LANES && !rc; ++j)
+            if (wm >> j & 1) rc = lane_order(c, st[L], st[j]);
+        if (rc) break;
+        c->ws = (char*)c->ws_base + (size_t)L * c->ws_bytes;
+        const bool timed = ev && (!rec || (ops[i].flags & 0x80));      // run_program_ev brackets only ops with flags bit 7
+        if (rec) rec[i] = timed;
+        if (timed) IFCBK_HIP(c, hipEventRecord(ev[2 * i], st[L]));
+        rc = run_one(c, &ops[i], st[L]);
+        if (rc) {
+            size_t len = strlen(c->err);
+            snprintf(c->err + len, sizeof(c->err) - len, " [op %d kind %d]", i, ops[i].kind);
+            break;
+        }
+        if (timed) IFCBK_HIP(c, hipEventRecord(ev[2 * i + 1], st[L]));
+    }
+    c->ws = c->ws_base;
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)                                // join, also on the error path
+        if (used >> l & 1) (void)lane_order(c, s0, st[l]);
+    return rc;
+}
+
 extern "C" int ifcbk_run_program(ifcbk_ctx* c, const ifcbk_op* ops, int n, void* stream, float* op_ms) {
     if (!c || (!ops && n > 0)) return IFCBK_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (op_ms) {
-        if (c->n_ev < n + 1) {
-            hipEvent_t* ev = (hipEvent_t*)realloc(c->ev, sizeof(hipEvent_t) * (n + 1));
+        if (c->n_ev < 2 * n) {
+            hipEvent_t* ev = (hipEvent_t*)realloc(c->ev, sizeof(hipEvent_t) * (2 * n));
             if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "run_program: event pool");
             c->ev = ev;
-            for (int i = c->n_ev; i < n + 1; ++i) IFCBK_HIP(c, hipEventCreate(&c->ev[i]));
-            c->n_ev = n + 1;
+            for (int i = c->n_ev; i < 2 * n; ++i) IFCBK_HIP(c, hipEventCreate(&c->ev[i]));
+            c->n_ev = 2 * n;
         }
-        IFCBK_HIP(c, hipEventRecord(c->ev[0], st));
     }
-    for (int i = 0; i < n; ++i) {
-        int e = run_one(c, &ops[i], stream);
-        if (e) {
-            size_t L = strlen(c->err);
-            snprintf(c->err + L, sizeof(c->err) - L, " [op %d kind %d]", i, ops[i].kind);
-            return e;
-        }
-        if (op_ms) IFCBK_HIP(c, hipEventRecord(c->ev[i + 1], st));
-    }
+    if (int e = run_lanes(c, ops, n, st, op_ms ? c->ev : nullptr)) return e;
     if (op_ms) {
         IFCBK_HIP(c, hipStreamSynchronize(st));
-        for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->ev[i], c->ev[i + 1]));
+        for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->ev[2 * i], c->ev[2 * i + 1]));
     }
     return IFCBK_OK;
 }
-
 extern "C" int ifcbk_run_program_ev(ifcbk_ctx* c, const ifcbk_op* ops, int n, void* stream, int slot) {
     if (!c || slot < 0 || slot >= 256 || (!ops && n > 0)) return IFCBK_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    if (c->slot_n[slot] < n + 1) {
-        hipEvent_t* ev = (hipEvent_t*)realloc(c->slot_ev[slot], sizeof(hipEvent_t) * (n + 1));
+    if (c->slot_n[slot] < 2 * n) {
+        hipEvent_t* ev = (hipEvent_t*)realloc(c->slot_ev[slot], sizeof(hipEvent_t) * (2 * n));
         if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "run_program_ev: event pool");
         c->slot_ev[slot] = ev;
-        for (int i = c->slot_n[slot]; i < n + 1; ++i) IFCBK_HIP(c, hipEventCreate(&ev[i]));
-        c->slot_n[slot] = n + 1;
+        for (int i = c->slot_n[slot]; i < 2 * n; ++i) IFCBK_HIP(c, hipEventCreate(&ev[i]));
+        c->slot_n[slot] = 2 * n;
+        unsigned char* r = (unsigned char*)realloc(c->slot_rec[slot], n > 0 ? n : 1);
+        if (!r) IFCBK_FAIL(c, IFCBK_ENOMEM, "run_program_ev: event pool");
+        c->slot_rec[slot] = r;
     }
-    hipEvent_t* ev = c->slot_ev[slot];
-    IFCBK_HIP(c, hipEventRecord(ev[0], st));
-    for (int i = 0; i < n; ++i) {
-        int e = run_one(c, &ops[i], stream);
-        if (e) return e;
-        IFCBK_HIP(c, hipEventRecord(ev[i + 1], st));
-    }
-    return IFCBK_OK;
+    memset(c->slot_rec[slot], 0, n);
+    return run_lanes(c, ops, n, (hipStream_t)stream, c->slot_ev[slot], c->slot_rec[slot]);
 }
-
 extern "C" int ifcbk_program_times(ifcbk_ctx* c, int slot, int n, float* op_ms) {
-    if (!c || slot < 0 || slot >= 256 || !op_ms || c->slot_n[slot] < n + 1) return IFCBK_EINVAL;
-    for (int i = 0; i < n; ++i) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->slot_ev[slot][i], c->slot_ev[slot][i + 1]));
+    if (!c || slot < 0 || slot >= 256 || !op_ms || c->slot_n[slot] < 2 * n) return IFCBK_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        op_ms[i] = 0.f;
+        if (c->slot_rec[slot][i]) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->slot_ev[slot][2 * i], c->slot_ev[slot][2 * i + 1]));
+    }
     return IFCBK_OK;
 }
 

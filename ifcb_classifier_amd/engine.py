@@ -20,13 +20,19 @@ def _vp(t, byte_off=0):
 
 
 class OpList:
+    """ops + tags + scheduling metadata: (lane, reads, writes) per op.  A resource is (key..., lo, hi): a channel range
+    of a tensor.  An op without annotations is a full barrier on lane 0 (loss, head, Adam, pack ...)."""
+
     def __init__(self):
         self.ops = []
         self.tags = []
+        self.meta = []
 
-    def add(self, kind, tag, p=(), i=(), f=(), flags=0, conv=None, bn=None, pool=None, head=None):
+    def add(self, kind, tag, p=(), i=(), f=(), flags=0, conv=None, bn=None, pool=None, head=None, lane=0, reads=None,
+            writes=None):
         o = Op()
         o.kind, o.flags = kind, flags
+        self.meta.append((lane, reads, writes))
         for k, v in enumerate(p):
             o.p[k] = v if (v is None or isinstance(v, int)) else v.value
         for k, v in enumerate(i):
@@ -48,10 +54,70 @@ class OpList:
     def extend(self, other):
         self.ops.extend(other.ops)
         self.tags.extend(other.tags)
+        self.meta.extend(other.meta)
+
+    def slice(self, b0, b1):
+        sub = OpList()
+        sub.ops, sub.tags, sub.meta = self.ops[b0:b1], self.tags[b0:b1], self.meta[b0:b1]
+        return sub
 
     def freeze(self):
         arr = (Op * len(self.ops))(*self.ops)
+        for k, (lane, wait) in enumerate(schedule_lanes(self.meta)):
+            arr[k].flags = (arr[k].flags & 0xff) | (lane << 8) | (wait << 12)
         return arr
+
+
+def _overlap(a, b):
+    return a[:-2] == b[:-2] and a[-2] < b[-1] and b[-2] < a[-1]
+
+
+def schedule_lanes(meta):
+    """(lane, wait mask) per op from the static data flow: an op waits for the lanes that hold an unfinished producer of
+    something it reads, or an unfinished reader / writer of something it writes.  A wait covers everything queued on the
+    waited lane so far (and, transitively, whatever that lane had waited for), which is remembered to skip redundant waits."""
+    NL = 4
+    count = [0] * NL                              # ops queued per lane
+    synced = [[0] * NL for _ in range(NL)]        # synced[L][j]: lane L is ordered after the first synced[L][j] ops of lane j
+    table = {}                                    # resource -> [writer (lane, pos) or None, readers [(lane, pos)]]
+    star = ('*', 0, 1)
+    out = []
+    for lane, reads, writes in meta:
+        if reads is None and writes is None:
+            lane, reads, writes = 0, [star], [star]           # barrier
+        else:
+            reads, writes = list(reads or ()) + [star], list(writes or ())
+        deps = set()
+        for r in reads:
+            for res, (w, _rd) in table.items():
+                if w is not None and _overlap(r, res):
+                    deps.add(w)
+        for wres in writes:
+            for res, (w, rd) in table.items():
+                if _overlap(wres, res):
+                    if w is not None:
+                        deps.add(w)
+                    deps.update(rd)
+        wait = 0
+        for (lj, pj) in deps:
+            if lj != lane and pj >= synced[lane][lj]:
+                wait |= 1 << lj
+        for lj in range(NL):
+            if wait >> lj & 1:
+                synced[lane][lj] = count[lj]
+                for k in range(NL):
+                    if k != lane:
+                        synced[lane][k] = max(synced[lane][k], synced[lj][k])
+        me = (lane, count[lane])
+        count[lane] += 1
+        for r in reads:
+            table.setdefault(r, [None, []])[1].append(me)
+        for wres in writes:
+            for res in [res for res in table if _overlap(wres, res)]:
+                table[res] = [me, []]
+            table[wres] = [me, []]
+        out.append((lane, wait))
+    return out
 
 
 class Program:
@@ -59,9 +125,22 @@ class Program:
         self.tags = list(oplist.tags)
         self.n = len(oplist.ops)
         self.arr = oplist.freeze()
+        self.lanes = sorted({m[0] for m in oplist.meta if not (m[1] is None and m[2] is None)} | {0})
 
     def find(self, kind):
         return [k for k in range(self.n) if self.arr[k].kind == kind]
+
+    def timed(self, which=None, single_lane=False):
+        """a copy of the op table in which the ops `which` (indices; None = all) carry flags bit 7: ifcbk_run_program_ev
+        brackets exactly those with HIP events.  single_lane: drop the lane / wait bits, i.e. run every op back to back
+        on the caller's stream (per-kernel durations without another lane's kernel sharing the GPU)"""
+        arr = (Op * self.n)(*self.arr)
+        for k in (range(self.n) if which is None else which):
+            arr[k].flags |= 0x80
+        if single_lane:
+            for k in range(self.n):
+                arr[k].flags &= 0xff
+        return arr
 
 
 class Engine:
@@ -252,12 +331,13 @@ class Engine:
                 continue
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
         max_raw = max(n.P * n.Q * n.K for n in self.convs)
-        self.draw = torch.zeros(N * max_raw, dtype=bf, device=dev)
+        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2'))))      # program lanes (branch-parallel streams)
+        self.draw = [torch.zeros(N * max_raw, dtype=bf, device=dev) for _ in range(self.NL)]
         gmax = max([g.x.H * g.x.W * g.Ktot for g in self.groups] + [0])
         self.draw_group = torch.zeros(max(1, N * gmax), dtype=bf, device=dev)
         mb = max([self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs] +
                  [self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._group_desc(g, N))) * 2 * g.Ktot for g in self.groups])
-        self.bn_part = torch.zeros(mb, dtype=torch.float32, device=dev)
+        self.bn_part = [torch.zeros(mb, dtype=torch.float32, device=dev) for _ in range(self.NL)]
         self.argmax = {}
         for k, n in enumerate(net.nodes):
             if n.kind == 'max':
@@ -286,7 +366,7 @@ class Engine:
     def activation_bytes(self):
         tot = sum(t.numel() * t.element_size() for t in self.act.values())
         tot += sum(t.numel() * t.element_size() for t in self.grad.values())
-        return tot + self.draw.numel() * self.esize
+        return tot + sum(t.numel() for t in self.draw) * self.esize
 
     # ------------------------------------------------------------------ descriptors
     def _conv_desc(self, n, N):
@@ -359,9 +439,48 @@ class Engine:
         fused_pool_nodes = {v[0] for v in fused_pool.values()}
         self.fused_pool = fused_pool
 
+        # ---- lanes: every chain of nodes that hangs off a shared tensor (an Inception block input, a resnet block
+        # input) gets a lane, round-robin; a node fed by a private tensor stays on its producer's lane
+        NL = self.NL
+        producers = {}
+        for m in net.nodes:
+            if m.kind != 'head':
+                producers.setdefault(m.y.buf.id, []).append(m)
+        lane_of, started = {}, {}
+        for m in net.nodes:
+            if m.kind == 'head' or m.aux:
+                lane_of[m] = 0
+                continue
+            prods = producers.get(m.x.buf.id, [])
+            if (len(prods) == 1 and prods[0].y.is_full and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1
+                    and prods[0] in lane_of):
+                lane_of[m] = lane_of[prods[0]]
+            else:
+                kk = started.get(m.x.buf.id, 0)
+                started[m.x.buf.id] = kk + 1
+                lane_of[m] = kk % NL
+
+        # ---- resources for the lane scheduler: channel ranges of tensors
+        def ra(v):
+            return ('a', v.buf.id, v.coff, v.coff + v.C)
+
+        def rg(v):
+            return ('g', v.buf.id, v.coff, v.coff + v.C)
+
+        def rraw(m):
+            return ('gr', id(m.group), m.koff, m.koff + m.K) if m.group is not None else ('r', m.raw.id, 0, m.K)
+
+        def rdg(m):
+            return ('dg', id(m.group), m.koff, m.koff + m.K)
+
+        rst = lambda m: ('s', id(m), 0, 1)
+        rbp = lambda L: ('bp', L, 0, 1)
+        ram = lambda kk: ('am', kk, 0, 1)
+
         bwd_groups = []
         for k, n in enumerate(net.nodes):
             grp = OpList()
+            L = lane_of[n]
             if n.kind == 'conv':
                 M = N * n.P * n.Q
                 d = self._conv_desc(n, N)
@@ -385,7 +504,8 @@ class Engine:
                         # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
                         lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
                                 p=(self._aptr(n.x), wk, self._aptr(n.y), self._stat(n, 4), self._stat(n, 5), res),
-                                i=(ldr,), flags=4 if n.relu else 0, conv=d)
+                                i=(ldr,), flags=4 if n.relu else 0, conv=d, lane=L,
+                                reads=[ra(n.x)] + ([ra(n.residual)] if n.residual is not None else []), writes=[ra(n.y)])
                         continue
                     if g is not None:
                         if not first_of_group:
@@ -394,39 +514,41 @@ class Engine:
                         gd = self._group_desc(g, N)
                         gmb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(gd))
                         lst.add(_lib.OP_CONV_FWD, '+'.join(m.name for m in g.members),
-                                p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), _vp(g.raw), _vp(self.bn_part)),
-                                conv=gd)
+                                p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), _vp(g.raw), _vp(self.bn_part[0])),
+                                conv=gd, lane=0, reads=[ra(g.x)], writes=[('gr', id(g), 0, g.Ktot), rbp(0)])
                         for m in g.members:
                             mbk = m.bn_key
                             mraw, mld = self._raw_ptr(m)
                             mbnd = BnDesc(M, m.K, mld, m.y.buf.C, 1, self.cdtype, m.eps, 0.1)
                             lst.add(_lib.OP_BN_FINALIZE, m.name,
-                                    p=(_vp(self.bn_part, 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
+                                    p=(_vp(self.bn_part[0], 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
                                        _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
                                        self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
-                                    i=(gmb, g.Ktot), bn=mbnd)
+                                    i=(gmb, g.Ktot), bn=mbnd, lane=lane_of[m], reads=[rbp(0)], writes=[rst(m)])
                             lst.add(_lib.OP_BN_APPLY, m.name,
-                                    p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd)
+                                    p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd,
+                                    lane=lane_of[m], reads=[rraw(m), rst(m)], writes=[ra(m.y)])
                         continue
-                    lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part) if train else None),
-                            conv=dfw)
+                    lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part[L]) if train else None),
+                            conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
                     if train:
                         lst.add(_lib.OP_BN_FINALIZE, n.name,
-                                p=(_vp(self.bn_part), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
+                                p=(_vp(self.bn_part[L]), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
                                    _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
                                    self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3)),
-                                i=(mb,), bn=bnd)
+                                i=(mb,), bn=bnd, lane=L, reads=[rbp(L)], writes=[rst(n)])
                     if train and n in fused_pool:
                         pn, pk = fused_pool[n]
                         ppd = PoolDesc(N, pn.x.H, pn.x.W, pn.x.C, ldraw, 3, 3, 2, 2, pn.ph, pn.pw, pn.P, pn.Q, pn.y.buf.C,
                                        self.cdtype)
                         lst.add(_lib.OP_BN_APPLY_MAXPOOL, n.name + '+' + pn.name,
                                 p=(raw, self._stat(n, 2), self._stat(n, 3), self._aptr(pn.y), _vp(self.argmax[pk])),
-                                i=(1,), pool=ppd)
+                                i=(1,), pool=ppd, lane=L, reads=[rraw(n), rst(n)], writes=[ra(pn.y), ram(pk)])
                         continue
                     lst.add(_lib.OP_BN_APPLY, n.name,
                             p=(raw, self._stat(n, 2 if train else 4), self._stat(n, 3 if train else 5), res, self._aptr(n.y)),
-                            i=(ldr,), bn=bnd)
+                            i=(ldr,), bn=bnd, lane=L, reads=[rraw(n), rst(n)] + ([ra(n.residual)] if n.residual is not None else []),
+                            writes=[ra(n.y)])
                 evalprep.add(_lib.OP_BN_FINALIZE, n.name,
                              p=(None, self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
                                 _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
@@ -434,7 +556,7 @@ class Engine:
                 needs_dgrad = not n.x.buf.is_input
                 pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), i=(n.wT_ld,), conv=d)
                 # ---- backward of this node
-                draw = _vp(self.draw) if g is None else _vp(self.draw_group, self.esize * n.koff)
+                draw = _vp(self.draw[L]) if g is None else _vp(self.draw_group, self.esize * n.koff)
                 dres, lddres, dres_acc = None, 0, 0
                 # (flags resolved later, in reverse order) -> store a closure
                 bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad))
@@ -447,9 +569,11 @@ class Engine:
                     if n.kind == 'max':
                         if train and n in fused_pool_nodes:
                             continue              # done by the producing conv's bn_apply_maxpool
-                        lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd)
+                        lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd,
+                                lane=L, reads=[ra(n.x)], writes=[ra(n.y), ram(k)])
                     else:
-                        lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd)
+                        lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd,
+                                lane=L, reads=[ra(n.x)], writes=[ra(n.y)])
                 bwd_groups.append(('pool', n, pd, k))
             elif n.kind == 'head':
                 hd = HeadDesc(N, n.HW, n.C, n.x.buf.C, n.NC, self.cdtype, 2.0)
@@ -480,9 +604,11 @@ class Engine:
                     continue                      # gathered inside the producer's bn_bwd_maxpool
                 acc = acc_flag(n.x.buf)
                 if n.kind == 'max':
-                    bwd.add(_lib.OP_MAXPOOL_BWD, n.name, p=(self._aptr(n.y, True), _vp(self.argmax[k]), self._aptr(n.x, True)), flags=acc, pool=pd)
+                    bwd.add(_lib.OP_MAXPOOL_BWD, n.name, p=(self._aptr(n.y, True), _vp(self.argmax[k]), self._aptr(n.x, True)), flags=acc, pool=pd,
+                            lane=lane_of[n], reads=[rg(n.y), ram(k)], writes=[rg(n.x)])
                 else:
-                    bwd.add(_lib.OP_AVGPOOL_BWD, n.name, p=(self._aptr(n.y, True), self._aptr(n.x, True)), flags=acc, pool=pd)
+                    bwd.add(_lib.OP_AVGPOOL_BWD, n.name, p=(self._aptr(n.y, True), self._aptr(n.x, True)), flags=acc, pool=pd,
+                            lane=lane_of[n], reads=[rg(n.y)], writes=[rg(n.x)])
             else:
                 _, n, d, bnd, draw, wT, needs_dgrad = g
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
@@ -492,6 +618,8 @@ class Engine:
                     dres_acc = acc_flag(n.residual.buf)
                     dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
                 grp = n.group
+                L = lane_of[n]
+                rdraw = [rdg(n)] if grp is not None else []      # the per-lane d(raw) scratch is ordered by its stream
                 rawp, _ld = self._raw_ptr(n)
                 if n in fused_pool:
                     pn, pk = fused_pool[n]
@@ -500,33 +628,39 @@ class Engine:
                             p=(rawp, self._aptr(pn.y, True), _vp(self.argmax[pk]), self._pptr(bkey + '.weight'),
                                self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3), draw,
                                self._pptr(bkey + '.weight', 'G'), self._pptr(bkey + '.bias', 'G')),
-                            i=(1, n.K), pool=ppd)
+                            i=(1, n.K), pool=ppd, lane=L, reads=[rraw(n), rg(pn.y), ram(pk), rst(n)], writes=rdraw)
                 else:
                     bwd.add(_lib.OP_BN_BWD, n.name,
                             p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
                                self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
                                self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
-                            i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd)
+                            i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd, lane=L,
+                            reads=[rraw(n), ra(n.y), rg(n.y), rst(n)],
+                            writes=rdraw + ([rg(n.residual)] if n.residual is not None else []))
                 if grp is not None:
                     # fused siblings: every member's d(raw) lands in its slice of the merged scratch; the member that
                     # comes FIRST in forward order is the last one here and launches the single wgrad + dgrad
                     if grp.members[0] is n:
                         gd = self._group_desc(grp, N)
                         gp = [_vp(self.draw_group)] + [self._pptr(m.conv_key + '.weight', 'G') for m in grp.members]
+                        gres = ('dg', id(grp), 0, grp.Ktot)
                         bwd.add(_lib.OP_CONV_WGRAD_SEG, '+'.join(m.name for m in grp.members),
-                                p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd)
+                                p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd,
+                                lane=0, reads=[ra(grp.x), gres], writes=[])
                         acc = acc_flag(grp.x.buf)
                         bwd.add(_lib.OP_CONV_DGRAD, '+'.join(m.name for m in grp.members),
                                 p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
-                                flags=acc, conv=gd)
+                                flags=acc, conv=gd, lane=0, reads=[gres], writes=[rg(grp.x)])
                     continue
                 dbw = ConvDesc.from_buffer_copy(d)
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
-                bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw)
+                bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
+                        lane=L, reads=[ra(n.x)], writes=[])
                 if needs_dgrad:
                     assert n.x.is_full
                     acc = acc_flag(n.x.buf)
-                    bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw)
+                    bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw,
+                            lane=L, reads=[], writes=[rg(n.x)])
 
         class PlanObj:
             pass
@@ -621,9 +755,7 @@ class Engine:
         ops = pl.bwd_list.ops
         segs = []
         for (b0, b1, lo, hi) in segment_plan([self._op_param_offsets(o) for o in ops], padded, self.nparam_padded, nseg):
-            sub = OpList()
-            sub.ops, sub.tags = ops[b0:b1], pl.bwd_list.tags[b0:b1]
-            segs.append((Program(sub), b1, lo, hi))
+            segs.append((Program(pl.bwd_list.slice(b0, b1)), b1, lo, hi))
         pl.ddp_segs = segs
         return segs
 
@@ -733,7 +865,7 @@ class Engine:
         self.packed = False
         self.eval_stats_ready = False
 
-    def train_step(self, N, op_ms=None, ev_slot=None):
+    def train_step(self, N, op_ms=None, ev_slot=None, ev_arr=None):
         """one fused launch list: fwd + CE(+0.4 aux) + bwd + Adam + weight repack; loss stays on device."""
         pl = self.plan(N)
         self.ensure_packed(pl)
@@ -741,7 +873,13 @@ class Engine:
         self.step_count += 1
         pl.step.arr[pl.step_adam_idx].i[1] = self.step_count
         if ev_slot is not None:
-            self.ctx.call('ifcbk_run_program_ev', pl.step.arr, pl.step.n, self.stream(), int(ev_slot))
+            # ev_arr: pl.step.timed(...) -- which ops to bracket with HIP events (default: all)
+            if ev_arr is None:
+                if getattr(pl, 'step_timed_all', None) is None:
+                    pl.step_timed_all = pl.step.timed()
+                ev_arr = pl.step_timed_all
+            ev_arr[pl.step_adam_idx].i[1] = self.step_count
+            self.ctx.call('ifcbk_run_program_ev', ev_arr, pl.step.n, self.stream(), int(ev_slot))
         else:
             self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)
         self.nbt += 1

@@ -238,7 +238,10 @@ enum {
 };
 typedef struct {
     int32_t kind;
-    int32_t flags;           /* accumulate etc. (per kind)                                            */
+    int32_t flags;           /* bit 0 accumulate, bit 1 param accumulate, bit 2 relu (per kind);
+                              * bits 8-9 LANE of this op (0 = the caller's stream, 1-3 = ctx-owned streams),
+                              * bits 12-15 WAIT mask: lanes whose queued work must finish before this op starts.
+                              * All lanes start after the caller's prior work and join lane 0 at program end. */
     void*   p[12];           /* pointer operands in the order of the typed entry point               */
     int64_t i[4];            /* scalar ints (per kind)                                                */
     float   f[8];            /* scalar floats (per kind)                                              */
@@ -252,9 +255,10 @@ typedef struct {
 /* op_ms (nullable, host array of n floats): when given, every op is bracketed by HIP events on
  * `stream`, the stream is synchronised at the end and per-op milliseconds are returned.             */
 int ifcbk_run_program(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, float* op_ms);
-/* Non-blocking timing: same launches, with HIP events recorded on `stream` around every op into event
- * slot `slot` (0..255, one slot per in-flight program run); nothing is synchronised.  After the caller has
- * synchronised the stream, ifcbk_program_times returns the n per-op milliseconds of that slot.           */
+/* Non-blocking timing: same launches, with HIP events recorded (on the op's lane) around every op whose flags
+ * have bit 7 set, into event slot `slot` (0..255, one slot per in-flight program run); nothing is synchronised.  After the caller has
+ * synchronised the stream, ifcbk_program_times returns the n per-op milliseconds of that slot (0 for ops
+ * that were not bracketed).                                                                              */
 int ifcbk_run_program_ev(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, int slot);
 int ifcbk_program_times(ifcbk_ctx*, int slot, int n, float* op_ms);
 /* name of the (dominant) device kernel an op launches, e.g. "conv_igemm_bf16<4>" (as rocprofv3 prints it
