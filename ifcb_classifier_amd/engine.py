@@ -330,10 +330,13 @@ class Engine:
             if b.name.endswith(':raw'):
                 continue
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
-        max_raw = max(n.P * n.Q * n.K for n in self.convs)
         self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2'))))      # program lanes (branch-parallel streams)
         self.wgrad_side_lane = os.environ.get('IFCBK_WGRAD_SIDE', '0') != '0' and self.NL > 1
-        self.draw = [torch.zeros(N * max_raw, dtype=bf, device=dev) for _ in range(self.NL)]
+        self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
+        max_raw = max(n.P * n.Q * n.K for n in self.convs)
+        # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
+        # the next node's BN backward already fills the other)
+        self.draw = [torch.zeros(N * max_raw, dtype=bf, device=dev) for _ in range(self.NL * (2 if self.wgrad_side_lane else 1))]
         gmax = max([g.x.H * g.x.W * g.Ktot for g in self.groups] + [0])
         self.draw_group = torch.zeros(max(1, N * gmax), dtype=bf, device=dev)
         mb = max([self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs] +
@@ -557,10 +560,11 @@ class Engine:
                 needs_dgrad = not n.x.buf.is_input
                 pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), i=(n.wT_ld,), conv=d)
                 # ---- backward of this node
-                draw = _vp(self.draw[L]) if g is None else _vp(self.draw_group, self.esize * n.koff)
+                di = L * 2 + (k & 1) if self.wgrad_side_lane else L
+                draw = _vp(self.draw[di]) if g is None else _vp(self.draw_group, self.esize * n.koff)
                 dres, lddres, dres_acc = None, 0, 0
                 # (flags resolved later, in reverse order) -> store a closure
-                bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad))
+                bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad, di))
             elif n.kind in ('max', 'avg'):
                 pd = PoolDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q, n.y.buf.C,
                               self.cdtype)
@@ -611,7 +615,7 @@ class Engine:
                     bwd.add(_lib.OP_AVGPOOL_BWD, n.name, p=(self._aptr(n.y, True), self._aptr(n.x, True)), flags=acc, pool=pd,
                             lane=lane_of[n], reads=[rg(n.y)], writes=[rg(n.x)])
             else:
-                _, n, d, bnd, draw, wT, needs_dgrad = g
+                _, n, d, bnd, draw, wT, needs_dgrad, di = g
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 dres, lddres, dres_acc = None, 0, 0
                 if n.residual is not None:
@@ -620,7 +624,7 @@ class Engine:
                     dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
                 grp = n.group
                 L = lane_of[n]
-                rdraw = [rdg(n)] if grp is not None else [('draw', L, 0, 1)]     # d(raw): merged-group slice or the lane's scratch
+                rdraw = [rdg(n)] if grp is not None else [('draw', di, 0, 1)]     # d(raw): merged-group slice or the lane's scratch
                 rawp, _ld = self._raw_ptr(n)
                 if n in fused_pool:
                     pn, pk = fused_pool[n]
@@ -658,7 +662,8 @@ class Engine:
                 # wgrad and dgrad only share their input d(raw); IFCBK_WGRAD_SIDE=1 puts the weight gradient on the neighbouring
                 # lane -- measured slower (31.5 vs 29.1 ms/step): the next node's bn_bwd must wait for it to release the scratch
                 bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
-                        lane=(L + 1) % NL if self.wgrad_side_lane else L, reads=[ra(n.x)] + rdraw, writes=[])
+                        lane=(L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L,
+                        reads=[ra(n.x)] + rdraw, writes=[])
                 if needs_dgrad:
                     assert n.x.is_full
                     acc = acc_flag(n.x.buf)
