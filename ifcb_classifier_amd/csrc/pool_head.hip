@@ -484,27 +484,35 @@ __global__ void dropout_mask_kernel(uint8_t* mask, int64_t n, float p, uint64_t 
 }
 
 // ---------------------------------------------------------------- loss (single block: deterministic mean)
-__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits, const int64_t* target, int N, int NC,
-                                                           float weight, float* loss_out, int loss_acc, float* dlogits) {
+// 4 lanes per sample (classes j = sub, sub+4, ...: adjacent lanes read adjacent logits), fixed butterfly for max and
+// sum, per-sample losses summed in a fixed order by thread 0 -> bitwise reproducible.
+__global__ __launch_bounds__(1024) void softmax_xent_kernel(const float* logits, const int64_t* target, int N, int NC,
+                                                            float weight, float* loss_out, int loss_acc, float* dlogits) {
     __shared__ float sl[256];
-    float local = 0.f;
+    const int sub = threadIdx.x & 3, slot = threadIdx.x >> 2;
     const float invN = 1.f / (float)N;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        const float* l = logits + (size_t)n * NC;
+    float local = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+        const int n = n0 + slot;
+        const bool ok = n < N;
+        const float* l = logits + (size_t)(ok ? n : 0) * NC;
         float mx = -INFINITY;
-        for (int j = 0; j < NC; ++j) mx = fmaxf(mx, l[j]);
+        for (int j = sub; j < NC; j += 4) mx = fmaxf(mx, l[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
         float s = 0.f;
-        for (int j = 0; j < NC; ++j) s += expf(l[j] - mx);
-        float lse = mx + logf(s);
-        int tg = (int)target[n];
-        local += lse - l[tg];
-        if (dlogits) {
+        for (int j = sub; j < NC; j += 4) s += expf(l[j] - mx);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const int tg = ok ? (int)target[n] : 0;
+        if (ok && sub == 0) local += mx + logf(s) - l[tg];
+        if (ok && dlogits) {
             float* d = dlogits + (size_t)n * NC;
-            float is = 1.f / s;
-            for (int j = 0; j < NC; ++j) d[j] = weight * invN * (expf(l[j] - mx) * is - (j == tg ? 1.f : 0.f));
+            const float is = 1.f / s;
+            for (int j = sub; j < NC; j += 4) d[j] = weight * invN * (expf(l[j] - mx) * is - (j == tg ? 1.f : 0.f));
         }
     }
-    sl[threadIdx.x] = local;
+    if (sub == 0) sl[slot] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
         float s = 0.f;
@@ -712,7 +720,7 @@ extern "C" int ifcbk_dropout_mask(ifcbk_ctx* ctx, uint8_t* mask, int64_t n, floa
 extern "C" int ifcbk_softmax_xent(ifcbk_ctx* ctx, const float* logits, const int64_t* target, int N, int NC, float weight,
                                   float* loss_out, int loss_accumulate, float* dlogits, void* stream) {
     if (N <= 0 || NC <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "softmax_xent: empty");
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, ST, logits, target, N, NC, weight, loss_out, loss_accumulate, dlogits);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(1024), 0, ST, logits, target, N, NC, weight, loss_out, loss_accumulate, dlogits);
     IFCBK_LAUNCH_CHECK(ctx, "softmax_xent");
     return 0;
 }
