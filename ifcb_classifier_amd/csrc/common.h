@@ -77,12 +77,18 @@ template <> struct Chunk<bf16_t> {
     __device__ static __forceinline__ void load(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
     __device__ static __forceinline__ void store(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
     __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }      // the value as it would be stored
+    typedef uint4 raw_t;                                                                    // a chunk as loaded, not yet widened
+    __device__ static __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ static __forceinline__ void widen(const raw_t& r, float* f) { unpack8(r, f); }
 };
 template <> struct Chunk<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void load(const float* p, float* f) { *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p); }
     __device__ static __forceinline__ void store(float* p, const float* f) { *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(f); }
     __device__ static __forceinline__ float round(float v) { return v; }
+    typedef float4 raw_t;
+    __device__ static __forceinline__ raw_t load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void widen(const raw_t& r, float* f) { *reinterpret_cast<float4*>(f) = r; }
 };
 __device__ __forceinline__ float to_f32(bf16_t v) { return bf2f(v); }
 __device__ __forceinline__ float to_f32(float v) { return v; }
