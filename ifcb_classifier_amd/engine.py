@@ -452,7 +452,10 @@ class Engine:
                 producers.setdefault(m.y.buf.id, []).append(m)
         lane_of, started = {}, {}
         for m in net.nodes:
-            if m.kind == 'head' or m.aux:
+            if m.aux:
+                lane_of[m] = 1 % NL       # the auxiliary classifier (pool, 2 convs, fc) runs beside Mixed_7a..7c
+                continue
+            if m.kind == 'head':
                 lane_of[m] = 0
                 continue
             prods = producers.get(m.x.buf.id, [])
@@ -587,7 +590,8 @@ class Engine:
                     if n.aux and not train:
                         continue
                     mask = _vp(n.mask) if (train and n.dropout) else None
-                    lst.add(_lib.OP_HEAD_FWD, n.name, p=(self._aptr(n.x), mask, self._pptr(wkey), self._pptr(bkey), _vp(n.feat), _vp(n.logits)), head=hd)
+                    lst.add(_lib.OP_HEAD_FWD, n.name, p=(self._aptr(n.x), mask, self._pptr(wkey), self._pptr(bkey), _vp(n.feat), _vp(n.logits)), head=hd,
+                            lane=L, reads=[ra(n.x)], writes=[('hd', id(n), 0, 1)])
                 bwd_groups.append(('head', n, hd))
 
         # backward in reverse node order, resolving first-writer / accumulate flags
@@ -601,7 +605,7 @@ class Engine:
                 bwd.add(_lib.OP_HEAD_BWD, n.name,
                         p=(_vp(n.dlogits), _vp(n.feat), _vp(n.mask) if n.dropout else None, self._pptr(wkey),
                            self._pptr(wkey, 'G'), self._pptr(bkey, 'G'), self._aptr(n.x, True)),
-                        i=(n.x.buf.C,), head=hd)
+                        i=(n.x.buf.C,), head=hd, lane=lane_of[n], reads=[('hd', id(n), 0, 1)], writes=[rg(n.x)])
             elif g[0] == 'pool':
                 _, n, pd, k = g
                 assert n.x.is_full
@@ -729,7 +733,7 @@ class Engine:
                 it.K, it.RS, it.C, it.Cw = d.K, d.R * d.S, d.C, d.Cw
                 it.wT_ld = int(o.i[0])
                 it.first_block = blk
-                blk += (d.K * d.R * d.S * d.C + 255) // 256
+                blk += ((d.K + 31) // 32) * d.R * d.S * ((d.C + 31) // 32)      # 32x32 (k, c) tiles per filter tap
             raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
             self._pack_items = torch.from_numpy(raw).to(self.dev)
             self._pack_n, self._pack_blocks = len(pack.ops), blk

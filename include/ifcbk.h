@@ -98,7 +98,7 @@ typedef struct {
     void*   w;               /* shadow [K][R][S][C]                                                   */
     void*   wT;              /* flipped/transposed shadow [C][R][S][K] or NULL                        */
     int32_t K, RS, C, Cw;
-    int64_t first_block;     /* index of this item's first 256-thread block in the launch             */
+    int64_t first_block;     /* index of this item's first block; an item has cdiv(K,32)*RS*cdiv(C,32) blocks  */
     int32_t wT_ld;           /* 0: K; >0: row stride of wT (this conv is a K-slice of a fused filter)  */
     int32_t pad_;
 } ifcbk_pack_item;
