@@ -141,6 +141,12 @@ template <> struct ArgPack<4> {
     }
 };
 
+// conv_rows.hip: direct 3x3/stride-1 convolution of the narrow stem layers
+bool ifcbk_conv_rows_ok(int dtype, int cin, int cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int Wout);
+int ifcbk_conv_rows_blocks(int N, int Pout);
+int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int W, int ldx, int P, int Q, int ldy, int pad_h,
+                           int pad_w, const void* x, const void* w, void* y, float* part, const float* scale,
+                           const float* shift, int relu, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K);
 int ifcbk_conv_fwd_wm(int M, int K);
 void ifcbk_conv_wgrad_shape(const ifcbk_conv_desc* d, int* mt, int* cols);

@@ -501,7 +501,12 @@ int ifcbk_conv_fwd_nt(int K) { return pick_nt(K, pick_wm(0, K) == 4 ? 5 : 6); }
 
 int ifcbk_conv_fwd_wm(int M, int K) { return pick_wm(M, K); }
 
+static bool fwd_rows(const ifcbk_conv_desc* d) {
+    return ifcbk_conv_rows_ok(d->dtype, d->C, d->K, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->Q);
+}
+
 extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
+    if (fwd_rows(d)) return ifcbk_conv_rows_blocks(d->N, d->P);
     int M = d->N * d->P * d->Q;
     return cdiv(M, 64 * pick_wm(M, d->K));
 }
@@ -524,6 +529,9 @@ extern "C" int ifcbk_conv2d_fwd_affine(ifcbk_ctx* ctx, const ifcbk_conv_desc* d,
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
+    if (fwd_rows(d) && !residual)
+        return ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,
+                                      bn_part, scale, shift, relu, (hipStream_t)stream);
     ConvArgs a;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
@@ -543,6 +551,10 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
 extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
                                   int accumulate, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
+    // the input gradient of a 3x3/stride-1 conv is a 3x3/stride-1 conv of dy with the flipped filter (wT), padding 2 - pad
+    if (!accumulate && ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W))
+        return ifcbk_conv_rows_launch(ctx, d->K, d->C, d->N, d->P, d->Q, d->ldy, d->H, d->W, d->ldx, 2 - d->pad_h, 2 - d->pad_w, dy,
+                                      wT, dx, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;

@@ -1,0 +1,235 @@
+// Direct 3x3 / stride-1 convolution for the narrow stem layers (32 or 64 input channels): forward of Conv2d_2a / 2b,
+// input gradient of both (a 3x3 convolution of dy with the flipped filter).
+//
+// As an implicit GEMM these layers re-read every input pixel 9 times from L2 for a 128 x 32 tile (25 flop per loaded
+// byte; 268-386 TF/s, 1.9 TB/s of L2->LDS traffic -- DESIGN.md 5.1).  Here a block walks down the output rows of one
+// image: each INPUT row is brought to LDS once (LDS-DMA, zero-filled outside the image by the buffer range check), stays
+// for the three output rows that use it (4-slot ring, the next row is in flight while a row is multiplied), and all nine
+// taps are MFMA operands read at shifted pixel addresses.  The filter lives in registers (MFMA A operand, loaded once
+// per block), an input fragment feeds COUT/16 MFMAs.  Epilogue as in conv_igemm: output row through LDS, 16-byte stores,
+// BatchNorm statistics of the ROUNDED outputs (one partial row per block), optional eval-BN affine + ReLU.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct RowsArgs {
+    const void* x;
+    const void* w;          // [COUT][3][3][CIN]
+    void* y;
+    float* part;            // [blocks][2][COUT] or null
+    const float* ep_scale;
+    const float* ep_shift;
+    int ep_relu;
+    unsigned xbytes;
+    int N, H, W, ldx, P, Q, ldy, ph, pw;
+    int rseg, nseg, mtiles;
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int RSEG = 16;        // output rows per block
+constexpr int MT_MAX = 10;      // 16-pixel tiles per output row (Q <= 160)
+constexpr int NPX = 16 * MT_MAX + 4;   // pixels of an LDS row image: input columns -2 .. 16*MT_MAX+1
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_rows3x3(RowsArgs a) {
+    constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel
+    constexpr int NTL = COUT / 16;                   // output-channel tiles
+    constexpr int KG = CIN / 32;                     // MFMA k groups per tap
+    constexpr int LDC = COUT + 8;
+    constexpr int CPO = COUT / 8;                    // chunks per output pixel
+    constexpr int NDMA = (NPX * CPP + 63) / 64;      // LDS-DMA wave-instructions per input row
+    constexpr int JD = (NDMA + 3) / 4;               // per wave
+    constexpr int SLOT = NDMA * 512;                 // elements per row slot: whole DMA pieces (the tail piece writes zeros)
+    // 4 slots: the next input row is in flight while a row is multiplied.  64 input channels: 3 slots (the next row is
+    // requested right after the multiply and lands during the epilogue) so that two blocks still fit a CU
+    constexpr int NSLOT = CIN == 32 ? 4 : 3;
+    __shared__ __attribute__((aligned(16))) bf16_t sRow[NSLOT * SLOT];
+    __shared__ __attribute__((aligned(16))) bf16_t sC[16 * MT_MAX * LDC];
+    __shared__ float sRed[4][2][COUT];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / a.nseg;
+    const int p0 = (bid - n * a.nseg) * a.rseg;
+    const int p1 = min(p0 + a.rseg, a.P);
+
+    // ---- filter fragments (MFMA A operand): lane (row l&15, k group l>>4) of tile nt holds 8 input channels of a tap
+    const int frow = lane & 15, fkg = lane >> 4;
+    bf16x8_t wf[9][NTL][KG];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+                wf[tap][nt][kg] = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)a.w + ((size_t)(nt * 16 + frow) * 9 + tap) * CIN + kg * 32 + fkg * 8);
+
+    // ---- LDS-DMA of one input row: lane -> (pixel, chunk); LDS pixel index = input column + 2
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    int dcol[JD];                 // byte offset of this lane's chunk inside an input row, or -1
+    bool dlive[JD];               // this wave issues instruction j
+#pragma unroll
+    for (int j = 0; j < JD; ++j) {
+        const int inst = j * 4 + wave;
+        dlive[j] = inst < NDMA;
+        const int idx = inst * 64 + lane;            // position in the LDS image (chunk units)
+        const int px = idx / CPP;
+        const int phys = idx - px * CPP;
+        // source-side swizzle: the lane that lands on (px, phys) fetches logical chunk phys ^ f(px)
+        const int logical = CPP == 4 ? (phys ^ (((px >> 2) & 1) << 1)) : (phys ^ (px & 7));
+        const int wcol = px - 2;
+        dcol[j] = (px < NPX && wcol >= 0 && wcol < a.W) ? (wcol * a.ldx + logical * 8) * 2 : -1;
+    }
+    const int img = n * a.H;
+#define ISSUE_ROW(hin)                                                                                          \
+    {                                                                                                           \
+        const int h_ = (hin);                                                                                   \
+        const bool rowok = h_ >= 0 && h_ < a.H;                                                                 \
+        const unsigned rbase = (unsigned)((img + h_) * a.W * a.ldx) * 2u;                                       \
+        bf16_t* dst = sRow + ((h_ + 6) % NSLOT) * SLOT;                                                         \
+        _Pragma("unroll") for (int j = 0; j < JD; ++j)                                                          \
+            if (dlive[j]) {                                                                                     \
+                const unsigned vo = (rowok && dcol[j] >= 0) ? rbase + (unsigned)dcol[j] : OOB;                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + (j * 4 + wave) * 512), 16, vo, 0, 0, 0); \
+            }                                                                                                   \
+    }
+
+    // ---- per-lane fragment byte offsets of the pixel operand for the three column shifts
+    // pixel of lane = q0 + frow + s - pw + 2  (LDS index); chunk = kg*4 + fkg, swizzled by the pixel
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+
+    const int h_first = p0 - a.ph;
+    ISSUE_ROW(h_first)
+    ISSUE_ROW(h_first + 1)
+    ISSUE_ROW(h_first + 2)
+    for (int p = p0; p < p1; ++p) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // rows p-ph .. p-ph+2 are in LDS; sC of the previous row is consumed
+        if (NSLOT == 4 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // prefetch: its slot held row p-ph-1, no longer needed
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi) {
+            const int mt = wave + 4 * mi;
+            if (mt >= a.mtiles) break;
+            f32x4_t acc[NTL];
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bf16_t* rowp = sRow + ((p - a.ph + r + 6) % NSLOT) * SLOT;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int px = mt * 16 + frow + s - a.pw + 2;
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) {
+                        const int ch = kg * 4 + fkg;
+                        const int phys = CPP == 4 ? (ch ^ (((px >> 2) & 1) << 1)) : (ch ^ (px & 7));
+                        const bf16x8_t xb = *reinterpret_cast<const bf16x8_t*>(rowp + px * CIN + phys * 8);
+#pragma unroll
+                        for (int nt = 0; nt < NTL; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r * 3 + s][nt][kg], xb, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            // lane holds channels nt*16 + 4*(lane>>4) .. +3 of pixel mt*16 + frow
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                uint2 u;
+                u.x = pack2bf(acc[nt][0], acc[nt][1]);
+                u.y = pack2bf(acc[nt][2], acc[nt][3]);
+                *reinterpret_cast<uint2*>(sC + (mt * 16 + frow) * LDC + nt * 16 + 4 * fkg) = u;
+            }
+        }
+        __syncthreads();
+        if (NSLOT == 3 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // the slot of row p-ph is free: every wave is past its multiply
+        // ---- output row: 16-byte chunks, thread t always owns channel chunk t % CPO
+        {
+            const int cc = t % CPO;
+            const int nn = cc * 8;
+            float sc[8], sh[8];
+            if (a.ep_scale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sc[j] = a.ep_scale[nn + j]; sh[j] = a.ep_shift[nn + j]; }
+            }
+            bf16_t* yrow = (bf16_t*)a.y + ((size_t)(n * a.P + p) * a.Q) * a.ldy + nn;
+            for (int q = t / CPO; q < a.Q; q += 256 / CPO) {
+                float fv[8];
+                Chunk<bf16_t>::load(sC + q * LDC + nn, fv);
+                if (a.part) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s1[j] += fv[j]; s2[j] += fv[j] * fv[j]; }
+                }
+                if (a.ep_scale) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        fv[j] = fv[j] * sc[j] + sh[j];
+                        if (a.ep_relu) fv[j] = fmaxf(fv[j], 0.f);
+                    }
+                }
+                Chunk<bf16_t>::store(yrow + (size_t)q * a.ldy, fv);
+            }
+        }
+    }
+#undef ISSUE_ROW
+    if (a.part) {
+        // threads with the same channel chunk (t % CPO) -> one partial row per block, fixed order
+#pragma unroll
+        for (int off = CPO; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1[j] += __shfl_xor(s1[j], off);
+                s2[j] += __shfl_xor(s2[j], off);
+            }
+        __syncthreads();
+        if (lane < CPO) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sRed[wave][0][lane * 8 + j] = s1[j];
+                sRed[wave][1][lane * 8 + j] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < 2 * COUT; i += 256) {
+            const int which = i / COUT, c = i - which * COUT;
+            a.part[((size_t)bid * 2 + which) * COUT + c] = (sRed[0][which][c] + sRed[1][which][c]) + (sRed[2][which][c] + sRed[3][which][c]);
+        }
+    }
+}
+
+bool enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("IFCBK_CONV_ROWS"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+}  // namespace
+
+// cin/cout: channels of the tensor that is READ / WRITTEN by this launch (swapped roles for the input gradient)
+bool ifcbk_conv_rows_ok(int dtype, int cin, int cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int Wout) {
+    if (!enabled() || dtype != IFCBK_BF16 || R != 3 || S != 3 || stride_h != 1 || stride_w != 1) return false;
+    if (!((cin == 32 && cout == 32) || (cin == 32 && cout == 64) || (cin == 64 && cout == 32))) return false;
+    return pad_h >= 0 && pad_h <= 2 && pad_w >= 0 && pad_w <= 2 && Wout <= 16 * MT_MAX && Wout >= 1;
+}
+
+int ifcbk_conv_rows_blocks(int N, int Pout) { return N * ((Pout + RSEG - 1) / RSEG); }
+
+// x: [N,H,W,ldx] read with `cin` channels; y: [N,P,Q,ldy] written with `cout` channels; w: [cout][3][3][cin]
+int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int W, int ldx, int P, int Q, int ldy, int pad_h,
+                           int pad_w, const void* x, const void* w, void* y, float* part, const float* scale,
+                           const float* shift, int relu, hipStream_t st) {
+    RowsArgs a;
+    a.x = x; a.w = w; a.y = y; a.part = part; a.ep_scale = scale; a.ep_shift = shift; a.ep_relu = relu;
+    a.xbytes = (unsigned)((int64_t)N * H * W * ldx * 2);
+    a.N = N; a.H = H; a.W = W; a.ldx = ldx; a.P = P; a.Q = Q; a.ldy = ldy; a.ph = pad_h; a.pw = pad_w;
+    a.rseg = RSEG; a.nseg = (P + RSEG - 1) / RSEG; a.mtiles = (Q + 15) / 16;
+    const dim3 grid(N * a.nseg), block(256);
+    if (cin == 32 && cout == 32) hipLaunchKernelGGL((conv_rows3x3<32, 32>), grid, block, 0, st, a);
+    else if (cin == 32 && cout == 64) hipLaunchKernelGGL((conv_rows3x3<32, 64>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_rows3x3<64, 32>), grid, block, 0, st, a);
+    IFCBK_LAUNCH_CHECK(ctx, "conv_rows3x3");
+    return 0;
+}

@@ -231,6 +231,9 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
+            if (ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]))
+                snprintf(name, cap, "conv_rows3x3<%d, %d>", d.C, d.K);
+            else
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
             break;
         }
@@ -238,6 +241,10 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.H * d.W, d.C);
             {
+                if (!(o->flags & 1) && ifcbk_conv_rows_ok(d.dtype, d.K, d.C, d.R, d.S, d.stride_h, d.stride_w, 2 - d.pad_h, 2 - d.pad_w, d.W)) {
+                    snprintf(name, cap, "conv_rows3x3<%d, %d>", d.K, d.C);
+                    break;
+                }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
                 snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, classes ? 2 : (s2 ? 1 : 0));

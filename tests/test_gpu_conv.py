@@ -51,6 +51,9 @@ CASES = [
     (2, 32, 13, 11, 48, 3, 3, 2, 2, 1, 1),         # odd, non-square input
     (1, 16, 8, 8, 16, 2, 2, 2, 2, 0, 0),           # 2x2 stride 2: one tap per class
     (1, 24, 9, 9, 40, 5, 5, 2, 2, 2, 2),           # 5x5 stride 2: 9 / 6 / 6 / 4 taps
+    (2, 32, 21, 19, 64, 3, 3, 1, 1, 1, 1),         # row-streaming stem kernel: 32 -> 64, pad 1 (dgrad 64 -> 32)
+    (1, 32, 20, 149, 32, 3, 3, 1, 1, 0, 0),        # ... full 149-wide rows (10 pixel tiles), two row segments
+    (3, 32, 35, 18, 32, 3, 3, 1, 1, 0, 0),         # ... three row segments per image
 ]
 
 
