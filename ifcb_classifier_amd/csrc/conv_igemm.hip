@@ -306,9 +306,10 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
         const int cc = t & (CPRP - 1);
         const int r0 = t / CPRP;
         const bool cvalid = (cc < CPR) && (n0 + cc * CE < a.K);
-        float s1[CE], s2[CE];
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t s1p[CE / 2], s2p[CE / 2];
 #pragma unroll
-        for (int j = 0; j < CE; ++j) s1[j] = s2[j] = 0.f;
+        for (int j = 0; j < CE / 2; ++j) s1p[j] = s2p[j] = f32x2_t{0.f, 0.f};
         if (cvalid) {
             const int nn = n0 + cc * CE;
             float sc[CE], sh[CE];
@@ -349,15 +350,23 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                     const int r = r0 + (b + u) * RPP;
                     const int m = m0 + r;
                     if (m >= a.M) break;
-                    float fv[CE];
-                    Chunk<T>::load(sC + r * LDC + cc * CE, fv);          // values as they are stored (rounded for bf16)
+                    // the chunk as it is stored (rounded for bf16): when nothing modifies it (training forward, first-writer
+                    // dgrad) the raw bits go straight to memory; the statistics use packed fp32 math (v_pk_add / v_pk_fma)
+                    const typename Chunk<T>::raw_t rawc = Chunk<T>::load_raw(sC + r * LDC + cc * CE);
                     T* dst = (T*)a.y + opx[u] * a.ldy + nn;
+                    float fv[CE];
+                    if (a.part || a.accumulate || a.ep_scale) Chunk<T>::widen(rawc, fv);
                     if (a.part) {
 #pragma unroll
-                        for (int j = 0; j < CE; ++j) {
-                            s1[j] += fv[j];
-                            s2[j] += fv[j] * fv[j];
+                        for (int j = 0; j < CE; j += 2) {
+                            const f32x2_t v = {fv[j], fv[j + 1]};
+                            s1p[j / 2] += v;
+                            s2p[j / 2] += v * v;
                         }
+                    }
+                    if (!(a.accumulate || a.ep_scale)) {
+                        *reinterpret_cast<typename Chunk<T>::raw_t*>(dst) = rawc;
+                        continue;
                     }
                     if (a.accumulate) {
                         float fo[CE];
@@ -385,6 +394,12 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
             }
         }
         if (a.part) {
+            float s1[CE], s2[CE];
+#pragma unroll
+            for (int j = 0; j < CE; ++j) {
+                s1[j] = s1p[j / 2][j & 1];
+                s2[j] = s2p[j / 2][j & 1];
+            }
 #pragma unroll
             for (int off = CPRP; off < 64; off <<= 1)
 #pragma unroll
