@@ -156,6 +156,164 @@ __device__ __forceinline__ void pooled_dy(const PoolGather& g, const T* dp, uint
         }
 }
 
+// Unpadded pools (inception): a thread takes a 2x2 block of input pixels.  The block meets only the windows
+// (hb-1..hb, wb-1..wb): four (arg-max, gradient) loads and four arg-max unpacks serve nine (pixel, window) incidences
+// instead of nine loads and unpacks -- the per-pixel gather above is VALU-bound (~160 instructions per 16-byte chunk).
+// fd[k]: pixel (2hb + k/2, 2wb + k%2).
+template <class T>
+__device__ __forceinline__ void pooled_dy_2x2(const PoolGather& g, const T* dp, uint32_t n, int hb, int wb, int c,
+                                              float (*fd)[Chunk<T>::N]) {
+    constexpr int E = Chunk<T>::N;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < E; ++j) fd[k][j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int p = hb - 1 + u, q = wb - 1 + v;
+            if (p < 0 || p >= g.P || q < 0 || q >= g.Q) continue;
+            const int64_t opix = (int64_t)(n * g.P + p) * g.Q + q;
+            int idx[E];
+            float f[E];
+            ArgPack<E>::load(g.arg + opix * g.C + c, idx);
+            Chunk<T>::load(dp + opix * g.ldp + c, f);
+            // window (u,v) holds pixel (a,b) of the block at tap (a + 2(1-u), b + 2(1-v)) when that is < 3
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int r = a + 2 * (1 - u), sx = b + 2 * (1 - v);
+                    if (r > 2 || sx > 2) continue;
+                    const int want = r * 3 + sx;
+#pragma unroll
+                    for (int j = 0; j < E; ++j)
+                        if (idx[j] == want) fd[a * 2 + b][j] += f[j];
+                }
+        }
+}
+
+template <class T, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool2x2_kernel(const T* x, int ldx, const T* dp, const float* mean,
+                                                                     const float* invstd, const float* scale, const float* shift,
+                                                                     float* part, int C, PoolGather pg, int HB, int WB,
+                                                                     uint32_t nblk, fastdiv_t fHBWB, fastdiv_t fWB) {
+    constexpr int E = Chunk<T>::N;
+    constexpr int CG = 8 * E;
+    constexpr int TILE = 256;                    // 2x2 blocks per partial row (1024 pixels)
+    __shared__ float red[4][2][CG];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cc = t & 7, r0 = t >> 3;
+    const int c = blockIdx.y * CG + cc * E;
+    const uint32_t bbeg = blockIdx.x * TILE;
+    const uint32_t bend = bbeg + TILE < nblk ? bbeg + TILE : nblk;
+    float sb[E], sg[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) sb[j] = sg[j] = 0.f;
+    if (c < C) {
+        float mu[E], is[E], sc[E], sh[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            mu[j] = mean[c + j];
+            is[j] = invstd[c + j];
+            sc[j] = MASK == 2 ? scale[c + j] : 0.f;
+            sh[j] = MASK == 2 ? shift[c + j] : 0.f;
+        }
+        for (uint32_t b = bbeg + r0; b < bend; b += 32) {
+            const uint32_t n = fdiv(b, fHBWB);
+            const uint32_t rem = b - n * fHBWB.d;
+            const int hb = (int)fdiv(rem, fWB);
+            const int wb = (int)rem - hb * WB;
+            float fd[4][E];
+            pooled_dy_2x2<T>(pg, dp, n, hb, wb, c, fd);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int h = 2 * hb + (k >> 1), w = 2 * wb + (k & 1);
+                if (h >= pg.H || w >= pg.W) continue;
+                float fx[E];
+                Chunk<T>::load(x + ((int64_t)(n * pg.H + h) * pg.W + w) * ldx + c, fx);
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    float dz = fd[k][j];
+                    if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
+                    sb[j] += dz;
+                    sg[j] += dz * ((fx[j] - mu[j]) * is[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            sb[j] += __shfl_xor(sb[j], off);
+            sg[j] += __shfl_xor(sg[j], off);
+        }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            red[wave][0][cc * E + j] = sb[j];
+            red[wave][1][cc * E + j] = sg[j];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * CG) {
+        int which = t / CG, nn = t - which * CG;
+        int ch = blockIdx.y * CG + nn;
+        if (ch < C) {
+            float s_ = red[0][which][nn] + red[1][which][nn] + red[2][which][nn] + red[3][which][nn];
+            part[((size_t)blockIdx.x * 2 + which) * C + ch] = s_;
+        }
+    }
+}
+
+template <class T, int MASK>
+__global__ __launch_bounds__(256) void bn_bwd_dx_pool2x2_kernel(const T* x, int ldx, const T* dp, const float* gamma,
+                                                                 const float* mean, const float* invstd, const float* scale,
+                                                                 const float* shift, const float* tmp, T* dx, int lddx, int C,
+                                                                 float invM, PoolGather pg, int HB, int WB, uint32_t total,
+                                                                 fastdiv_t fcpr, fastdiv_t fHBWB, fastdiv_t fWB) {
+    constexpr int E = Chunk<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float coef[];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float is = invstd[c], a_ = gamma[c] * is, dg = tmp[C + c] * invM, db = tmp[c] * invM;
+        coef[c] = a_;
+        coef[C + c] = -a_ * is * dg;
+        coef[2 * C + c] = a_ * (mean[c] * is * dg - db);
+        if (MASK == 2) {
+            coef[3 * C + c] = scale[c];
+            coef[4 * C + c] = shift[c];
+        }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t b = fdiv(i, fcpr);
+    const int c = (int)(i - b * fcpr.d) * E;
+    const uint32_t n = fdiv(b, fHBWB);
+    const uint32_t rem = b - n * fHBWB.d;
+    const int hb = (int)fdiv(rem, fWB);
+    const int wb = (int)rem - hb * WB;
+    float fd[4][E];
+    pooled_dy_2x2<T>(pg, dp, n, hb, wb, c, fd);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = 2 * hb + (k >> 1), w = 2 * wb + (k & 1);
+        if (h >= pg.H || w >= pg.W) continue;
+        const int64_t pix = (int64_t)(n * pg.H + h) * pg.W + w;
+        float fx[E], o[E];
+        Chunk<T>::load(x + pix * ldx + c, fx);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            float dz = fd[k][j];
+            if (MASK == 2) dz = (fx[j] * coef[3 * C + c + j] + coef[4 * C + c + j]) > 0.f ? dz : 0.f;
+            o[j] = coef[c + j] * dz + (coef[C + c + j] * fx[j] + coef[2 * C + c + j]);
+        }
+        Chunk<T>::store(dx + pix * lddx + c, o);
+    }
+}
+
 // ---------------------------------------------------------------- backward
 // pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks x 32 rows in flight
 constexpr int BWD_ROWS = 1024;
@@ -353,6 +511,29 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
     const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
     if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
+    if (pool && pg.ph == 0 && pg.pw == 0) {
+        if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
+        const int HB = (pg.H + 1) / 2, WB = (pg.W + 1) / 2;
+        const int64_t nblk = (int64_t)(M / ((int64_t)pg.H * pg.W)) * HB * WB;
+        const int64_t tot = nblk * (C / E);
+        if (tot >= (1ll << 31) - 256) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: tensor too large");
+        const int nt2 = cdiv(nblk, 256);
+        if (((size_t)nt2 * 2 * C + 2 * C) * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_maxpool: workspace");
+        float* tmp2 = part + (size_t)nt2 * 2 * C;
+        const fastdiv_t fHBWB = make_fastdiv(HB * WB), fWB = make_fastdiv(WB), fc2 = make_fastdiv(C / E);
+        dim3 g2(nt2, cdiv(C, CG));
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 2>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
+        else hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 0>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
+        IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce_pool2x2");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate);
+        IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
+        const float invM2 = (float)(1.0 / (double)M);
+        const size_t shm2 = (size_t)5 * C * sizeof(float);
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_dx_pool2x2_kernel<T, 2>), dim3(cdiv(tot, 256)), dim3(256), shm2, st, xx, d->ldx, dd, gamma, mean, invstd, scale, shift, (const float*)tmp2, (T*)dx, lddx, C, invM2, pg, HB, WB, (uint32_t)tot, fc2, fHBWB, fWB);
+        else hipLaunchKernelGGL((bn_bwd_dx_pool2x2_kernel<T, 0>), dim3(cdiv(tot, 256)), dim3(256), shm2, st, xx, d->ldx, dd, gamma, mean, invstd, scale, shift, (const float*)tmp2, (T*)dx, lddx, C, invM2, pg, HB, WB, (uint32_t)tot, fc2, fHBWB, fWB);
+        IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx_pool2x2");
+        return 0;
+    }
     if (pool) {
         if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
         if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);

@@ -175,7 +175,7 @@ def test_bn_fwd_bwd_vs_oracle(ctx, N, Cc, H, W, ld, relu, res):
 
 
 @pytest.mark.parametrize('N,Cc,H,W,pad,dtype', [(3, 64, 21, 21, 0, 0), (2, 192, 15, 13, 0, 0), (2, 64, 16, 16, 1, 0),
-                                               (2, 32, 9, 12, 1, 1)])
+                                               (2, 32, 9, 12, 1, 1), (2, 32, 11, 14, 0, 1), (1, 64, 147, 147, 0, 0)])
 def test_bn_maxpool_fused_equals_unfused(ctx, N, Cc, H, W, pad, dtype):
     """ifcbk_bn_apply_maxpool == bn_apply -> maxpool_fwd bit for bit (values and arg-max), and ifcbk_bn_bwd_maxpool ==
     maxpool_bwd -> bn_bwd: bit for bit in fp32 storage; in bf16 storage the unfused path rounds the (never stored here)
@@ -222,9 +222,9 @@ def test_bn_maxpool_fused_equals_unfused(ctx, N, Cc, H, W, pad, dtype):
     torch.cuda.synchronize()
     assert torch.equal(yp, yp2)
     assert torch.equal(arg, arg2)
-    if dtype:
-        assert torch.equal(dg, dg2) and torch.equal(db, db2)
-        assert torch.equal(dx, dx2)
+    if dtype:        # fp32 storage: identical terms, summed in a different order (2x2 pixel blocks) in the unpadded fast path
+        for a, b in ((dg, dg2), (db, db2), (dx, dx2)):
+            assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
     else:
         for a, b in ((dg, dg2), (db, db2), (dx.float(), dx2.float())):
             assert (a - b).abs().max().item() <= 1e-2 * a.abs().max().item()
