@@ -126,11 +126,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+    if 'IFCBK_BENCH_DEVICE' in os.environ:      # rehearsal of the N>1 path on a one-GPU box: every rank on the same device
+        local = int(os.environ['IFCBK_BENCH_DEVICE'])
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('IFCBK_BENCH_BACKEND', 'nccl')         # 'gloo' for the one-GPU rehearsal
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
 
     from ifcb_classifier_amd import graph, _lib
     from ifcb_classifier_amd.engine import Engine
@@ -144,7 +150,8 @@ def main():
     rois, _ = synth_rois(B, 1234 + rank, eng.dev)
     eng.target[:B].copy_(torch.randint(0, args.classes, (B,), generator=torch.Generator().manual_seed(99 + rank)))
     pl = eng.plan(B)
-    use_ev = (not args.no_events) and world == 1 and args.steps <= 256
+    do_survey = (not args.no_events) and args.steps <= 256
+    use_ev = do_survey and world == 1        # events in the timed region: single-GPU runs only (the N>1 step is several programs)
 
     def allred(t):
         return dist.all_reduce(t, async_op=True)
@@ -190,16 +197,22 @@ def main():
     # (each kernel alone on the GPU) and the dominant conv kernel.  Bracketing all ~560 ops costs ~1.7 ms per step, so the
     # timed region below brackets the dominant kernel only -- there on 2 lanes, i.e. as the step really runs.
     survey, ev_dom, dom = None, None, None
-    if use_ev:
+    if do_survey:
         NS = 3
         ev_all = pl.step.timed(single_lane=True)
         for k in range(NS):
-            step(k, ev_all)
+            eng.load_rois(**rois)
+            eng.train_step(B, ev_slot=k, ev_arr=ev_all)      # N>1: three LOCAL steps (no all-reduce) ...
         torch.cuda.synchronize()
+        if world > 1:                                         # ... then every replica is put back on rank 0's state
+            for buf in (eng.P, eng.M, eng.V, eng.RB):
+                dist.broadcast(buf, 0)
+            eng.params_changed()
         survey = op_table(NS)
         conv = {k: v for k, v in survey.items() if k.startswith('conv_')}
         dom = max(conv, key=lambda k: conv[k]['ms'])
-        ev_dom = pl.step.timed([j for j in range(pl.step.n) if kernel_of(j) == dom])
+        if use_ev:
+            ev_dom = pl.step.timed([j for j in range(pl.step.n) if kernel_of(j) == dom])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,8 +275,9 @@ def main():
             out.update({'infer_images_per_s': round(world * B * n_inf / dti, 1),
                         'infer_ms_per_batch': round(1e3 * dti / n_inf, 3),
                         'infer_mfma_frac': round(world * B * n_inf / dti * 11.423e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4)})
-        if use_ev:
-            d = op_table(args.steps)[dom]          # the dominant kernel's launches INSIDE the timed region
+        if do_survey:
+            # N=1: the dominant kernel's launches INSIDE the timed region; N>1: its launches in the survey pass
+            d = op_table(args.steps)[dom] if use_ev else survey[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None
             try:        # HBM bytes per launch of the same kernel from the committed PMC passes (scripts/collect_traffic.py)
@@ -276,9 +290,10 @@ def main():
                                'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']),
                                'avg_launch_ms': round(d['ms'] / d['launches'], 5), 'launches': d['launches'],
                                'flops_per_launch': d['flops'] / d['launches'],
-                               'note': 'HIP events around every launch of this kernel in the timed region, on the lane it runs '
-                                       'on: with %d program lanes another branch\'s kernel usually shares the GPU during a '
-                                       'launch; isolated_* = the same launches back to back on one lane (survey pass)' % eng.NL,
+                               'note': ('HIP events around every launch of this kernel in the timed region, on the lane it runs '
+                                        'on: with %d program lanes another branch\'s kernel usually shares the GPU during a '
+                                        'launch; isolated_* = the same launches back to back on one lane (survey pass)' % eng.NL)
+                               if use_ev else 'N > 1: rank 0, untimed survey pass (3 local steps, every op bracketed, one lane)',
                                'isolated_tflops': round(survey[dom]['flops'] / (survey[dom]['ms'] * 1e-3) / 1e12, 2),
                                'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5)}
             conv = {k: v for k, v in survey.items() if k.startswith('conv_')}
