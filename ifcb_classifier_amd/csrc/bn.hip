@@ -16,7 +16,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
     const int ch = blockIdx.x * 16 + c;
     double a = 0.0, b = 0.0;
     if (ch < C) {
-        for (int mb = rg; mb < mblocks; mb += 64) {
+        // four row blocks per trip: the loads of a trip are independent (one memory round trip), the adds keep a fixed order
+        int mb = rg;
+        for (; mb + 192 < mblocks; mb += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[2 * u] = part[((size_t)(mb + 64 * u) * 2 + 0) * ldp + ch];
+                v[2 * u + 1] = part[((size_t)(mb + 64 * u) * 2 + 1) * ldp + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a += (double)v[2 * u];
+                b += (double)v[2 * u + 1];
+            }
+        }
+        for (; mb < mblocks; mb += 64) {
             a += (double)part[((size_t)mb * 2 + 0) * ldp + ch];
             b += (double)part[((size_t)mb * 2 + 1) * ldp + ch];
         }
@@ -391,11 +406,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + c;
     double a = 0.0, b = 0.0;
-    if (ch < C)
-        for (int i = rg; i < ntiles; i += 16) {
+    if (ch < C) {
+        int i = rg;
+        for (; i + 48 < ntiles; i += 64) {           // four tiles per trip: independent loads, fixed-order adds
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[2 * u] = part[((size_t)(i + 16 * u) * 2 + 0) * C + ch];
+                v[2 * u + 1] = part[((size_t)(i + 16 * u) * 2 + 1) * C + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a += (double)v[2 * u];
+                b += (double)v[2 * u + 1];
+            }
+        }
+        for (; i < ntiles; i += 16) {
             a += (double)part[((size_t)i * 2 + 0) * C + ch];
             b += (double)part[((size_t)i * 2 + 1) * C + ch];
         }
+    }
     s[0][rg][c] = a;
     s[1][rg][c] = b;
     __syncthreads();
