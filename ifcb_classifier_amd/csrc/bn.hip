@@ -523,7 +523,7 @@ template <class T>
 int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy, int lddy,
           const float* gamma, const float* mean, const float* invstd, void* dx, int lddx, void* dres, int lddres,
           int dres_accumulate, float* dgamma, float* dbeta, int param_accumulate, const float* scale, const float* shift,
-          hipStream_t st, const PoolGather* pool = nullptr) {
+          hipStream_t st, const PoolGather* pool = nullptr, const float* part_in = nullptr, int ntiles_in = 0) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;
     PoolGather pg = {};
@@ -564,7 +564,14 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_dx_pool2x2");
         return 0;
     }
-    if (pool) {
+    if (part_in) {
+        // the partial sums were produced by the epilogue of the consumer's input-gradient kernel (ifcbk_conv2d_dgrad_bnstat)
+        if (mask != 2 || dres) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: ReLU layer without residual, scale/shift required");
+        part = const_cast<float*>(part_in);
+        ntiles = ntiles_in;
+        tmp = (float*)ctx->ws;
+        if ((size_t)2 * C * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_partials: workspace");
+    } else if (pool) {
         if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
         if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
@@ -738,6 +745,20 @@ extern "C" int ifcbk_bn_apply_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, 
     else hipLaunchKernelGGL(bn_apply_maxpool_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), shm, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, argmax, a);
     IFCBK_LAUNCH_CHECK(ctx, "bn_apply_maxpool");
     return 0;
+}
+
+extern "C" int ifcbk_bn_bwd_partials(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* dy, int lddy,
+                                     const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                     const float* shift, const float* part, int ntiles, void* dx, int lddx, float* dgamma,
+                                     float* dbeta, int param_accumulate, void* stream) {
+    if (!d || !part || ntiles <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad args");
+    if (d->dtype == IFCBK_F32)
+        return bwd_t<float>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                            param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles);
+    if (d->dtype == IFCBK_BF16)
+        return bwd_t<bf16_t>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                             param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles);
+    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad dtype");
 }
 
 extern "C" int ifcbk_bn_bwd_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, const void* dpool,

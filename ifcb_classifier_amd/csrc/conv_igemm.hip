@@ -27,6 +27,12 @@ struct ConvArgs {
     const float* ep_shift;
     const void* ep_res;
     int ep_ldr, ep_relu;
+    // dgrad whose output is the gradient of ONE BatchNorm+ReLU activation: the epilogue also reduces that BN's backward
+    // sums (sum dz, sum dz*xhat, dz = dy where the activation was positive) into `part` -- the BN backward then needs no
+    // reduction pass of its own.  bs_raw: the BN's input (raw conv output of the producing layer), pixel stride bs_ld
+    const void* bs_raw;
+    const float *bs_mean, *bs_invstd, *bs_scale, *bs_shift;
+    int bs_ld;
     unsigned xbytes, wbytes;   // buffer-descriptor extents of x and w
     int H, W, C, ldx;
     int K, R, S;
@@ -91,6 +97,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <class T, int NT, int WM, int NSTAGE, int MODE>
 __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
     constexpr bool STRIDED = MODE == 1;
+    constexpr bool BSTAT = MODE == 3;              // plain dgrad + BN-backward sums of the producing layer in the epilogue
     constexpr int ES = (int)sizeof(T);
     constexpr int CE = 16 / ES;                        // elements per 16-byte chunk
     constexpr int BK = 128 / ES;                       // k elements per tile step (128-byte rows)
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
 
     // 1x1 filter without padding (most layers of the inception / resnet graphs): the gather is a plain row read --
     // per-lane offsets are constants and the k advance is a scalar (soffset): no per-step VALU address work at all
-    const bool plain = MODE == 0 && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    const bool plain = (MODE == 0 || MODE == 3) && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
     unsigned va[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) va[j] = bh[j] >= 0 ? (unsigned)(off0[j] + csrc * CE) * (unsigned)ES : OOB;
@@ -312,6 +319,16 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
         for (int j = 0; j < CE / 2; ++j) s1p[j] = s2p[j] = f32x2_t{0.f, 0.f};
         if (cvalid) {
             const int nn = n0 + cc * CE;
+            float bmu[CE], bis[CE], bsc[CE], bsh[CE];
+            if (BSTAT) {
+#pragma unroll
+                for (int j = 0; j < CE; ++j) {
+                    bmu[j] = a.bs_mean[nn + j];
+                    bis[j] = a.bs_invstd[nn + j];
+                    bsc[j] = a.bs_scale[nn + j];
+                    bsh[j] = a.bs_shift[nn + j];
+                }
+            }
             float sc[CE], sh[CE];
             if (a.ep_scale) {
 #pragma unroll
@@ -324,9 +341,9 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
             // whole batch are requested before the first is used -- one exposed memory latency per batch instead of per row
             // (an accumulating 1x1 dgrad into a 288-channel block input ran at 1.5 TB/s with a load -> wait -> store loop)
             constexpr int RT = BM / RPP;
-            constexpr int UB = RT < 8 ? RT : 8;
+            constexpr int UB = BSTAT ? 4 : (RT < 8 ? RT : 8);
             for (int b = 0; b < RT; b += UB) {
-                typename Chunk<T>::raw_t pre[UB], prer[UB];
+                typename Chunk<T>::raw_t pre[UB], prer[UB], prb[UB];
                 size_t opx[UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
@@ -343,6 +360,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                     if (m < a.M) {
                         if (a.accumulate) pre[u] = Chunk<T>::load_raw((const T*)a.y + opx[u] * a.ldy + nn);
                         if (a.ep_scale && a.ep_res) prer[u] = Chunk<T>::load_raw((const T*)a.ep_res + (size_t)m * a.ep_ldr + nn);
+                        if (BSTAT) prb[u] = Chunk<T>::load_raw((const T*)a.bs_raw + opx[u] * a.bs_ld + nn);
                     }
                 }
 #pragma unroll
@@ -356,7 +374,19 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                     T* dst = (T*)a.y + opx[u] * a.ldy + nn;
                     float fv[CE];
                     if (a.part || a.accumulate || a.ep_scale) Chunk<T>::widen(rawc, fv);
-                    if (a.part) {
+                    if (BSTAT) {
+                        float fx[CE];
+                        Chunk<T>::widen(prb[u], fx);
+#pragma unroll
+                        for (int j = 0; j < CE; j += 2) {
+                            const float d0 = (fx[j] * bsc[j] + bsh[j]) > 0.f ? fv[j] : 0.f;
+                            const float d1 = (fx[j + 1] * bsc[j + 1] + bsh[j + 1]) > 0.f ? fv[j + 1] : 0.f;
+                            const f32x2_t dz = {d0, d1};
+                            const f32x2_t xh = {(fx[j] - bmu[j]) * bis[j], (fx[j + 1] - bmu[j + 1]) * bis[j + 1]};
+                            s1p[j / 2] += dz;
+                            s2p[j / 2] += dz * xh;
+                        }
+                    } else if (a.part) {
 #pragma unroll
                         for (int j = 0; j < CE; j += 2) {
                             const f32x2_t v = {fv[j], fv[j + 1]};
@@ -470,7 +500,8 @@ template <class T, int NT, int WM, int NSTAGE>
 void launch(const ConvArgs& a, hipStream_t st) {
     int tilesM = cdiv(a.M, 64 * WM);
     dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
-    if (a.wKg) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 2>), grid, block, 0, st, a);
+    if (a.bs_raw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 3>), grid, block, 0, st, a);
+    else if (a.wKg) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 2>), grid, block, 0, st, a);
     else if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 0>), grid, block, 0, st, a);
 }
@@ -550,6 +581,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     ConvArgs a;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
+    a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0;
     const int es = dtype_esize(d->dtype);
     a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * es);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
@@ -563,17 +595,57 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     return run(ctx, a, d->dtype, (hipStream_t)stream);
 }
 
+struct BnStatArgs {
+    const void* raw;
+    int ld;
+    const float *mean, *invstd, *scale, *shift;
+    float* part;
+};
+
+// the fused variant exists for the plain (stride-1, first-writer, implicit-GEMM) input gradient only
+static bool dgrad_bnstat_ok(const ifcbk_conv_desc* d) {
+    if (d->stride_h != 1 || d->stride_w != 1) return false;
+    return !ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W);
+}
+
+static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx, int accumulate,
+                      const BnStatArgs* bs, void* stream);
+
 extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
                                   int accumulate, void* stream) {
+    return dgrad_impl(ctx, d, dy, wT, dx, accumulate, nullptr, stream);
+}
+
+extern "C" int ifcbk_conv2d_dgrad_bnstat_mblocks(const ifcbk_conv_desc* d) {
+    if (!d || !dgrad_bnstat_ok(d)) return 0;
+    int M = d->N * d->H * d->W;
+    return cdiv(M, 64 * pick_wm(M, d->C));
+}
+
+extern "C" int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
+                                         const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
+                                         const float* prev_scale, const float* prev_shift, float* part, void* stream) {
+    if (!d || !dgrad_bnstat_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_dgrad_bnstat: stride-1 implicit-GEMM input gradients only");
+    if (!prev_raw || !prev_mean || !prev_invstd || !prev_scale || !prev_shift || !part)
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_dgrad_bnstat: null operand");
+    BnStatArgs bs = {prev_raw, prev_ld, prev_mean, prev_invstd, prev_scale, prev_shift, part};
+    return dgrad_impl(ctx, d, dy, wT, dx, 0, &bs, stream);
+}
+
+static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx, int accumulate,
+                      const BnStatArgs* bs, void* stream) {
     if (int e = check_desc(ctx, d)) return e;
     // the input gradient of a 3x3/stride-1 conv is a 3x3/stride-1 conv of dy with the flipped filter (wT), padding 2 - pad
-    if (!accumulate && ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W))
+    if (!bs && !accumulate && ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W))
         return ifcbk_conv_rows_launch(ctx, d->K, d->C, d->N, d->P, d->Q, d->ldy, d->H, d->W, d->ldx, 2 - d->pad_h, 2 - d->pad_w, dy,
                                       wT, dx, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
-    a.x = dy; a.w = wT; a.y = dx; a.part = nullptr;
+    a.x = dy; a.w = wT; a.y = dx; a.part = bs ? bs->part : nullptr;
+    a.bs_raw = bs ? bs->raw : nullptr; a.bs_ld = bs ? bs->ld : 0;
+    a.bs_mean = bs ? bs->mean : nullptr; a.bs_invstd = bs ? bs->invstd : nullptr;
+    a.bs_scale = bs ? bs->scale : nullptr; a.bs_shift = bs ? bs->shift : nullptr;
     const int es = dtype_esize(d->dtype);
     a.xbytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * es); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * es);
     a.H = d->P; a.W = d->Q; a.C = d->K; a.ldx = d->ldy;

@@ -88,6 +88,13 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_bn_bwd(c, &o->u.bn, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
                                 (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc, (float*)p[8], (float*)p[9],
                                 pacc, (const float*)p[10], (const float*)p[11], st);
+        case IFCBK_OP_CONV_DGRAD_BNSTAT:
+            return ifcbk_conv2d_dgrad_bnstat(c, &o->u.conv, p[0], p[1], p[2], p[3], (int)o->i[0], (const float*)p[4], (const float*)p[5],
+                                             (const float*)p[6], (const float*)p[7], (float*)p[8], st);
+        case IFCBK_OP_BN_BWD_PARTIALS:
+            return ifcbk_bn_bwd_partials(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                         (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], p[8], (int)o->i[2],
+                                         (float*)p[9], (float*)p[10], pacc, st);
         case IFCBK_OP_BN_APPLY_MAXPOOL:
             return ifcbk_bn_apply_maxpool(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (int)o->i[0], p[3], (uint8_t*)p[4], st);
         case IFCBK_OP_BN_BWD_MAXPOOL:
@@ -237,11 +244,11 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
             break;
         }
-        case IFCBK_OP_CONV_DGRAD: {
+        case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.H * d.W, d.C);
             {
-                if (!(o->flags & 1) && ifcbk_conv_rows_ok(d.dtype, d.K, d.C, d.R, d.S, d.stride_h, d.stride_w, 2 - d.pad_h, 2 - d.pad_w, d.W)) {
+                if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && ifcbk_conv_rows_ok(d.dtype, d.K, d.C, d.R, d.S, d.stride_h, d.stride_w, 2 - d.pad_h, 2 - d.pad_w, d.W)) {
                     snprintf(name, cap, "conv_rows3x3<%d, %d>", d.K, d.C);
                     break;
                 }
@@ -261,6 +268,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         }
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
+        case IFCBK_OP_BN_BWD_PARTIALS: snprintf(name, cap, "bn_bwd(partials)"); break;
         case IFCBK_OP_BN_APPLY_MAXPOOL: snprintf(name, cap, "bn_apply_maxpool_kernel"); break;
         case IFCBK_OP_BN_BWD_MAXPOOL: snprintf(name, cap, "bn_bwd(maxpool)"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;
@@ -280,17 +288,18 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
     double fl = 0, by = 0;
     switch (o->kind) {
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD:
-        case IFCBK_OP_CONV_WGRAD_SEG: {
+        case IFCBK_OP_CONV_WGRAD_SEG: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
             const ifcbk_conv_desc& d = o->u.conv;
             double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
             fl = 2.0 * mac;
             double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
                    wb = (double)d.K * d.R * d.S * d.C * 2;
-            by = xin + yout + wb;
+            by = xin + yout + wb + (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? xin : 0);      // + one read of the producer's raw output
             break;
         }
         case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;
         case IFCBK_OP_BN_BWD: by = (double)o->u.bn.M * o->u.bn.C * (2.0 * (o->u.bn.relu ? 6 : 4) + 2 + (o->p[7] ? 2 : 0)); break;
+        case IFCBK_OP_BN_BWD_PARTIALS: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + 2); break;      // x, dy in; dx out
         case IFCBK_OP_BN_APPLY_MAXPOOL: {
             const ifcbk_pool_desc& d = o->u.pool;
             by = ((double)d.N * d.H * d.W * 2 + (double)d.N * d.P * d.Q * 3) * d.C;      // x in; pooled y + u8 arg-max out

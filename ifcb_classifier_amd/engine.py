@@ -442,6 +442,22 @@ class Engine:
                         fused_pool[prod[0]] = (m, kk)
         fused_pool_nodes = {v[0] for v in fused_pool.values()}
         self.fused_pool = fused_pool
+        # conv c whose input is the private BN+ReLU activation of conv n: c's input-gradient kernel also reduces n's BN
+        # backward sums in its epilogue (ifcbk_conv2d_dgrad_bnstat) and n's BN backward skips its reduction pass
+        bnstat_of = {}        # consumer conv -> producer conv
+        if os.environ.get('IFCBK_FUSE_BNSTAT', '1') != '0':
+            for cnode in net.nodes:
+                if cnode.kind != 'conv' or cnode.group is not None or cnode.x.buf.is_input or not cnode.x.is_full:
+                    continue
+                if len(readers.get(cnode.x.buf.id, ())) != 1:
+                    continue
+                prod = [c for c in net.nodes if c.kind == 'conv' and c.y.buf.id == cnode.x.buf.id]
+                if (len(prod) == 1 and prod[0].y.is_full and prod[0].relu and prod[0].residual is None
+                        and prod[0] not in fused_pool and bool(prod[0].aux) == bool(cnode.aux)
+                        and self._conv_desc(cnode, N).C == cnode.x.C      # not the flattened full-cover form: its 'channels' are (tap, c)
+                        and self.ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(self._conv_desc(cnode, N))) > 0):
+                    bnstat_of[cnode] = prod[0]
+        bnstat_done = {}      # producer conv -> (partials pointer, row count, lane of the partial buffer)
 
         # ---- lanes: every chain of nodes that hangs off a shared tensor (an Inception block input, a resnet block
         # input) gets a lane, round-robin; a node fed by a private tensor stays on its producer's lane
@@ -638,6 +654,14 @@ class Engine:
                                self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3), draw,
                                self._pptr(bkey + '.weight', 'G'), self._pptr(bkey + '.bias', 'G')),
                             i=(1, n.K), pool=ppd, lane=L, reads=[rraw(n), rg(pn.y), ram(pk), rst(n)], writes=rdraw)
+                elif n in bnstat_done:
+                    ppart, nrow, pl_ = bnstat_done[n]
+                    bwd.add(_lib.OP_BN_BWD_PARTIALS, n.name,
+                            p=(rawp, self._aptr(n.y, True), self._pptr(bkey + '.weight'), self._stat(n, 0), self._stat(n, 1),
+                               self._stat(n, 2), self._stat(n, 3), ppart, draw, self._pptr(bkey + '.weight', 'G'),
+                               self._pptr(bkey + '.bias', 'G')),
+                            i=(n.y.buf.C, nrow, n.K if grp is None else grp.Ktot), bn=bnd, lane=L,
+                            reads=[rraw(n), rg(n.y), rst(n), rbp(pl_)], writes=rdraw)
                 else:
                     bwd.add(_lib.OP_BN_BWD, n.name,
                             p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
@@ -671,8 +695,18 @@ class Engine:
                 if needs_dgrad:
                     assert n.x.is_full
                     acc = acc_flag(n.x.buf)
-                    bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw,
-                            lane=L, reads=rdraw, writes=[rg(n.x)])
+                    if n in bnstat_of and acc == 0:
+                        pn = bnstat_of[n]
+                        prow, pld = self._raw_ptr(pn)
+                        nrow = self.ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(dbw))
+                        bwd.add(_lib.OP_CONV_DGRAD_BNSTAT, n.name,
+                                p=(draw, wT, self._aptr(n.x, True), prow, self._stat(pn, 0), self._stat(pn, 1),
+                                   self._stat(pn, 2), self._stat(pn, 3), _vp(self.bn_part[L])), i=(pld,), conv=dbw,
+                                lane=L, reads=rdraw + [rraw(pn), rst(pn)], writes=[rg(n.x), rbp(L)])
+                        bnstat_done[pn] = (_vp(self.bn_part[L]), nrow, L)
+                    else:
+                        bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw,
+                                lane=L, reads=rdraw, writes=[rg(n.x)])
 
         class PlanObj:
             pass
@@ -752,6 +786,8 @@ class Engine:
         if o.kind == _lib.OP_BN_BWD:
             return [(o.p[8] - base) // 4, (o.p[9] - base) // 4]
         if o.kind == _lib.OP_BN_BWD_MAXPOOL:
+            return [(o.p[9] - base) // 4, (o.p[10] - base) // 4]
+        if o.kind == _lib.OP_BN_BWD_PARTIALS:
             return [(o.p[9] - base) // 4, (o.p[10] - base) // 4]
         if o.kind == _lib.OP_HEAD_BWD:
             return [(o.p[4] - base) // 4, (o.p[5] - base) // 4]

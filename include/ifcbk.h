@@ -225,6 +225,23 @@ int ifcbk_bn_bwd_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, co
                          const float* scale, const float* shift, int relu, void* dx, int lddx, float* dgamma,
                          float* dbeta, int param_accumulate, void* stream);
 
+/* Input gradient of a stride-1 conv whose input is ONE BatchNorm+ReLU activation y = relu(bn(prev_raw)) with no other
+ * consumer: the epilogue that writes dx (= d loss / d y) also reduces that BatchNorm's backward sums (sum dz, sum dz*xhat
+ * per channel, dz = dx where y > 0) into `part` [mblocks][2][C] -- ifcbk_bn_bwd_partials then skips its reduction pass
+ * (one read of prev_raw in the epilogue replaces a pass over prev_raw and dx).  mblocks from ..._mblocks (0: this
+ * descriptor has no fused variant -- strided, or served by the row-streaming kernel).  Same results as
+ * ifcbk_conv2d_dgrad + ifcbk_bn_bwd up to the summation order of the two per-channel sums.
+ * Replaces autograd of [TV] BasicConv2d chains (inception.py), reference call site neuston_models.py:66-68,81-86.  */
+int ifcbk_conv2d_dgrad_bnstat_mblocks(const ifcbk_conv_desc*);
+int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
+                              const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
+                              const float* prev_scale, const float* prev_shift, float* part, void* stream);
+/* BatchNorm(+ReLU) backward from those partial sums: finalize + dx only                                        */
+int ifcbk_bn_bwd_partials(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* dy, int lddy,
+                          const float* gamma, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, const float* part, int ntiles, void* dx, int lddx, float* dgamma,
+                          float* dbeta, int param_accumulate, void* stream);
+
 /* ------------------------------------------------------------------ program runner
  * One call launches a whole forward / backward / update list: the host builds the op table once
  * (static graph), so the per-step host cost is one FFI crossing.                                     */
@@ -234,7 +251,8 @@ enum {
     IFCBK_OP_MAXPOOL_FWD, IFCBK_OP_MAXPOOL_BWD, IFCBK_OP_AVGPOOL_FWD, IFCBK_OP_AVGPOOL_BWD,
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
-    IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL
+    IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
+    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS
 };
 typedef struct {
     int32_t kind;

@@ -191,3 +191,50 @@ def test_conv_fp32_parity_mode(ctx, case):
     assert torch.allclose(part[:, 0].sum(0).cpu(), yh.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
     assert rel(dx.cpu().permute(0, 3, 1, 2), xr.grad) < 1e-5
     assert rel(dw.cpu(), wr.grad.permute(0, 2, 3, 1)) < 1e-5
+
+
+@pytest.mark.parametrize('case', [(2, 64, 9, 9, 96, 3, 3, 1, 1, 1, 1), (3, 192, 7, 7, 192, 1, 7, 1, 1, 0, 3),
+                                  (2, 48, 10, 10, 64, 5, 5, 1, 1, 2, 2), (5, 768, 5, 5, 128, 1, 1, 1, 1, 0, 0)])
+def test_dgrad_bnstat_equals_dgrad_then_bn_bwd(ctx, case):
+    """ifcbk_conv2d_dgrad_bnstat + ifcbk_bn_bwd_partials == ifcbk_conv2d_dgrad + ifcbk_bn_bwd: same dx of the conv (bit for
+    bit) and the same BatchNorm backward of the producing layer up to the summation order of the two channel sums."""
+    from ifcb_classifier_amd import _lib
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    g = torch.Generator().manual_seed(hash(case) % 997)
+    d = _desc(_lib, *case)
+    P, Q = d.P, d.Q
+    assert ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(d)) > 0
+    dy = _bf(torch.randn(N, P, Q, K, generator=g)).to(torch.bfloat16).cuda()
+    wT = _bf(torch.randn(Cc, R, S, K, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    raw = _bf(torch.randn(N, H, W, Cc, generator=g) * 1.5).to(torch.bfloat16).cuda()       # the producer's raw conv output
+    gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    mean = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    invstd = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    scale = (gamma * invstd).contiguous()
+    shift = (torch.randn(Cc, generator=g) * 0.3).cuda()
+    st = _lib.cur_stream()
+    M = N * H * W
+    bd = _lib.BnDesc(M, Cc, Cc, Cc, 1, 0, 1e-3, 0.1)
+    ctx.reserve(1 << 24)
+    # reference: two separate steps
+    dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_conv2d_dgrad', C.byref(d), _lib.ptr(dy), _lib.ptr(wT), _lib.ptr(dx), 0, st)
+    draw = torch.empty_like(dx)
+    dg, db = torch.zeros(Cc).cuda(), torch.zeros(Cc).cuda()
+    ctx.call('ifcbk_bn_bwd', C.byref(bd), _lib.ptr(raw), None, _lib.ptr(dx), Cc, _lib.ptr(gamma), _lib.ptr(mean),
+             _lib.ptr(invstd), _lib.ptr(draw), Cc, None, 0, 0, _lib.ptr(dg), _lib.ptr(db), 0, _lib.ptr(scale), _lib.ptr(shift), st)
+    # fused
+    nrow = ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(d))
+    part = torch.zeros(nrow, 2, Cc, device='cuda')
+    dx2 = torch.empty_like(dx)
+    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), _lib.ptr(dy), _lib.ptr(wT), _lib.ptr(dx2), _lib.ptr(raw), Cc,
+             _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(part), st)
+    draw2 = torch.empty_like(dx)
+    dg2, db2 = torch.zeros(Cc).cuda(), torch.zeros(Cc).cuda()
+    ctx.call('ifcbk_bn_bwd_partials', C.byref(bd), _lib.ptr(raw), _lib.ptr(dx2), Cc, _lib.ptr(gamma), _lib.ptr(mean),
+             _lib.ptr(invstd), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(part), nrow, _lib.ptr(draw2), Cc, _lib.ptr(dg2),
+             _lib.ptr(db2), 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)
+    for a, b in ((dg, dg2), (db, db2), (draw.float(), draw2.float())):
+        assert (a - b).abs().max().item() <= 2e-3 * a.abs().max().item() + 1e-6, (a - b).abs().max().item()
