@@ -1,0 +1,76 @@
+"""The lane scheduler (engine.schedule_lanes) must order every pair of conflicting ops: read-after-write, write-after-read
+and write-after-write on overlapping channel ranges, plus full barriers.  Checked on random programs by replaying the
+runner's semantics (ctx.hip::run_lanes): an op starts after the previous op of its lane and after everything queued so
+far on the lanes of its wait mask."""
+import random
+
+from ifcb_classifier_amd.engine import schedule_lanes, _overlap
+
+
+def _happens_before(sched):
+    n = len(sched)
+    last_on_lane = {}
+    preds = [set() for _ in range(n)]
+    queued = {l: [] for l in range(4)}
+    for i, (lane, wait) in enumerate(sched):
+        if lane in last_on_lane:
+            preds[i].add(last_on_lane[lane])
+        for l in range(4):
+            if wait >> l & 1 and queued[l]:
+                preds[i].add(queued[l][-1])          # the tail of lane l (stream order covers everything before it)
+        last_on_lane[lane] = i
+        queued[lane].append(i)
+    # transitive closure (small n)
+    reach = [set() for _ in range(n)]
+    for i in range(n):
+        for p in preds[i]:
+            reach[i].add(p)
+            reach[i] |= reach[p]
+    return reach
+
+
+def _random_program(rng, n, nl):
+    meta = []
+    for _ in range(n):
+        if rng.random() < 0.06:
+            meta.append((0, None, None))             # barrier op
+            continue
+        lane = rng.randrange(nl)
+
+        def res():
+            key = rng.choice(['a', 'g', 'r'])
+            buf = rng.randrange(4)
+            lo = rng.choice([0, 0, 64, 128])
+            hi = lo + rng.choice([64, 128, 256])
+            return (key, buf, lo, hi)
+        reads = [res() for _ in range(rng.randrange(0, 3))]
+        writes = [res() for _ in range(rng.randrange(0, 2))]
+        meta.append((lane, reads, writes))
+    return meta
+
+
+def test_schedule_orders_every_conflict():
+    rng = random.Random(1234)
+    for trial in range(60):
+        nl = rng.choice([1, 2, 3, 4])
+        meta = _random_program(rng, rng.randrange(5, 70), nl)
+        sched = schedule_lanes(meta)
+        assert len(sched) == len(meta)
+        reach = _happens_before(sched)
+        for j, (lj, rj, wj) in enumerate(meta):
+            for i in range(j):
+                li, ri, wi = meta[i]
+                barrier = (ri is None and wi is None) or (rj is None and wj is None)
+                conflict = barrier
+                if not barrier:
+                    for w in wi:
+                        conflict |= any(_overlap(w, x) for x in rj) or any(_overlap(w, x) for x in wj)
+                    for w in wj:
+                        conflict |= any(_overlap(w, x) for x in ri)
+                if conflict:
+                    assert i in reach[j], (trial, i, j, meta[i], meta[j], sched[i], sched[j])
+
+
+def test_single_lane_program_has_no_waits():
+    meta = [(0, [('a', 0, 0, 8)], [('a', 1, 0, 8)]), (0, [('a', 1, 0, 8)], [('a', 2, 0, 8)]), (0, None, None)]
+    assert schedule_lanes(meta) == [(0, 0), (0, 0), (0, 0)]
