@@ -225,3 +225,33 @@ def test_fp32_mode_meets_the_north_star_tolerance(name, nc, B, S):
         assert r < 1e-3
     finally:
         O.set_storage('bf16')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,B,S', [('inception_v3', 6, 299), ('resnet18', 8, 224)])
+def test_train_steps_are_bitwise_reproducible(name, B, S):
+    """Two replicas from the same seed, fed the same batches, stay bit-identical over several fused steps: every reduction
+    has a fixed order (no float atomics) and the program lanes are ordered by the static data flow -- a missing dependency
+    between lanes would show up here as diverging bits."""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    engs = []
+    for _ in range(2):
+        eng = Engine(graph.build(name, 7, pretrained=False), device=0, max_batch=B)
+        eng.init_weights(seed=4321)
+        engs.append(eng)
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        x = torch.rand(B, 3, S, S, generator=g)
+        y = torch.randint(0, 7, (B,), generator=g)
+        for eng in engs:
+            eng.load_input_nchw(x.cuda())
+            eng.target[:B].copy_(y)
+            if eng.heads[0].dropout or any(h.dropout for h in eng.heads):
+                eng.dropout_seed = 99          # same mask stream on both replicas
+            eng.train_step(B)
+        torch.cuda.synchronize()
+        assert torch.equal(engs[0].loss, engs[1].loss), step
+        assert torch.equal(engs[0].G, engs[1].G), step
+        assert torch.equal(engs[0].P, engs[1].P), step
+    assert torch.equal(engs[0].RB, engs[1].RB)
