@@ -112,6 +112,9 @@ _PROTOS = {
     'ifcbk_run_program': (_i, [_vp, C.POINTER(Op), _i, _vp, C.POINTER(_f)]),
     'ifcbk_run_program_ev': (_i, [_vp, C.POINTER(Op), _i, _vp, _i]),
     'ifcbk_program_times': (_i, [_vp, _i, _i, C.POINTER(_f)]),
+    'ifcbk_program_capture': (_i, [_vp, C.POINTER(Op), _i, C.POINTER(_vp)]),
+    'ifcbk_graph_launch': (_i, [_vp, _vp, _vp]),
+    'ifcbk_graph_destroy': (_i, [_vp, _vp]),
     'ifcbk_op_kernel': (_i, [C.POINTER(Op), C.c_char_p, _sz]),
     'ifcbk_op_cost': (_i, [C.POINTER(Op), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
@@ -158,6 +161,15 @@ class Context:
 
     def run_program(self, ops, n, stream, op_ms=None):
         self.call('ifcbk_run_program', ops, int(n), stream, op_ms)
+
+    def capture(self, ops, n):
+        """record a program into a hipGraph (nothing runs); returns the graph handle for ``graph_launch``."""
+        g = _vp()
+        self.call('ifcbk_program_capture', ops, int(n), C.byref(g))
+        return g
+
+    def graph_launch(self, g, stream):
+        self.call('ifcbk_graph_launch', g, stream)
 
     def __del__(self):
         try:

@@ -12,6 +12,7 @@ struct ifcbk_ctx {
     void* ws;            // workspace arena of the lane that is launching (split-K slabs, BN partials, resize tables)
     size_t ws_bytes;     // per lane
     void* ws_base;       // IFCBK_MAX_LANES arenas of ws_bytes each
+    unsigned ws_epoch;   // bumped when the arenas move: graphs captured before are stale
     hipStream_t lane_st[IFCBK_MAX_LANES];   // lanes 1.. of ifcbk_run_program (lane 0 is the caller's stream)
     hipEvent_t xev[64];  // cross-lane ordering events, used round-robin
     int n_xev, xev_next;

@@ -52,6 +52,7 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
     IFCBK_HIP(c, hipMalloc(&c->ws_base, bytes * IFCBK_MAX_LANES));     // one arena per program lane
     c->ws = c->ws_base;
     c->ws_bytes = bytes;
+    ++c->ws_epoch;
     return IFCBK_OK;
 }
 
@@ -140,11 +141,18 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
 static inline int op_lane(const ifcbk_op* o) { return (o->flags >> 8) & 3; }
 static inline int op_wait(const ifcbk_op* o) { return (o->flags >> 12) & 15; }
 
-static int lane_order(ifcbk_ctx* c, hipStream_t waiter, hipStream_t waited) {
+// streams and ordering events of the lanes in `used` (created outside of any stream capture)
+static int lane_resources(ifcbk_ctx* c, int used) {
     if (c->n_xev < 64) {
         for (int i = c->n_xev; i < 64; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
         c->n_xev = 64;
     }
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+        if ((used >> l & 1) && !c->lane_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
+    return IFCBK_OK;
+}
+
+static int lane_order(ifcbk_ctx* c, hipStream_t waiter, hipStream_t waited) {
     hipEvent_t ev = c->xev[c->xev_next];
     c->xev_next = (c->xev_next + 1) & 63;
     IFCBK_HIP(c, hipEventRecord(ev, waited));
@@ -157,9 +165,9 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
     hipStream_t st[IFCBK_MAX_LANES] = {s0, nullptr, nullptr, nullptr};
     int used = 1;
     for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
+    if (int e = lane_resources(c, used)) return e;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if (used >> l & 1) {
-            if (!c->lane_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
             st[l] = c->lane_st[l];
             if (int e = lane_order(c, st[l], s0)) return e;                 // fork: the lane starts after the caller's prior work
         }
@@ -228,6 +236,71 @@ extern "C" int ifcbk_program_times(ifcbk_ctx* c, int slot, int n, float* op_ms) 
         op_ms[i] = 0.f;
         if (c->slot_rec[slot][i]) IFCBK_HIP(c, hipEventElapsedTime(&op_ms[i], c->slot_ev[slot][2 * i], c->slot_ev[slot][2 * i + 1]));
     }
+    return IFCBK_OK;
+}
+
+// ---------------------------------------------------------------- hipGraph replay
+struct ifcbk_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    unsigned ws_epoch;
+    int n_ops;
+};
+
+extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, ifcbk_graph** out) {
+    if (!c || !out || !ops || n <= 0) return IFCBK_EINVAL;
+    *out = nullptr;
+    IFCBK_HIP(c, hipSetDevice(c->device));
+    int used = 1;
+    for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
+    if (int e = lane_resources(c, used)) return e;
+    // capture on a private stream: the caller's stream may be the legacy default stream, which cannot capture
+    hipStream_t cs = nullptr;
+    IFCBK_HIP(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipError_t he = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+    if (he != hipSuccess) {
+        (void)hipStreamDestroy(cs);
+        IFCBK_FAIL(c, IFCBK_EHIP, "program_capture: hipStreamBeginCapture: %s", hipGetErrorString(he));
+    }
+    const int rc = run_lanes(c, ops, n, cs, nullptr);            // records; the lanes fork from and join `cs`
+    hipGraph_t g = nullptr;
+    he = hipStreamEndCapture(cs, &g);                            // always ends the capture, also after a failed op
+    (void)hipStreamDestroy(cs);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (he != hipSuccess || !g) IFCBK_FAIL(c, IFCBK_EHIP, "program_capture: hipStreamEndCapture: %s", hipGetErrorString(he));
+    hipGraphExec_t x = nullptr;
+    he = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (he != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        IFCBK_FAIL(c, IFCBK_EHIP, "program_capture: hipGraphInstantiate: %s", hipGetErrorString(he));
+    }
+    ifcbk_graph* r = (ifcbk_graph*)calloc(1, sizeof(ifcbk_graph));
+    if (!r) {
+        (void)hipGraphExecDestroy(x);
+        (void)hipGraphDestroy(g);
+        IFCBK_FAIL(c, IFCBK_ENOMEM, "program_capture: out of host memory");
+    }
+    r->graph = g; r->exec = x; r->ws_epoch = c->ws_epoch; r->n_ops = n;
+    *out = r;
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_graph_launch(ifcbk_ctx* c, ifcbk_graph* g, void* stream) {
+    if (!c || !g) return IFCBK_EINVAL;
+    if (g->ws_epoch != c->ws_epoch) IFCBK_FAIL(c, IFCBK_EINVAL, "graph_launch: the workspace moved since this graph was captured; capture it again");
+    IFCBK_HIP(c, hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_graph_destroy(ifcbk_ctx* c, ifcbk_graph* g) {
+    (void)c;
+    if (!g) return IFCBK_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    free(g);
     return IFCBK_OK;
 }
 

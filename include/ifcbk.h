@@ -279,6 +279,17 @@ int ifcbk_run_program(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, floa
  * that were not bracketed).                                                                              */
 int ifcbk_run_program_ev(ifcbk_ctx*, const ifcbk_op* ops, int n, void* stream, int slot);
 int ifcbk_program_times(ifcbk_ctx*, int slot, int n, float* op_ms);
+/* hipGraph replay of a program (BASELINE config 4: "hipGraph-captured batches").  ifcbk_program_capture records the
+ * program's launches -- all lanes, with their fork / wait / join edges -- into a hipGraph through stream capture on a
+ * private stream (nothing executes) and instantiates it; ifcbk_graph_launch replays it stream-ordered on `stream`.
+ * Every pointer and scalar of the ops is baked in at capture time: the caller keeps the buffers alive and unmoved, and
+ * re-captures when a scalar changes (the engine keeps Adam, whose step count changes every step, outside the graph).
+ * The per-lane workspace arenas are baked in as well: ifcbk_ctx_reserve growing the workspace invalidates every graph
+ * of the ctx (ifcbk_graph_launch then fails with IFCBK_EINVAL instead of replaying stale pointers).                      */
+typedef struct ifcbk_graph ifcbk_graph;
+int ifcbk_program_capture(ifcbk_ctx*, const ifcbk_op* ops, int n, ifcbk_graph** out);
+int ifcbk_graph_launch(ifcbk_ctx*, ifcbk_graph*, void* stream);
+int ifcbk_graph_destroy(ifcbk_ctx*, ifcbk_graph*);
 /* name of the (dominant) device kernel an op launches, e.g. "conv_igemm_bf16<4>" (as rocprofv3 prints it
  * inside its mangled/demangled symbol); returns 0 and "" for ops without a compute kernel               */
 int ifcbk_op_kernel(const ifcbk_op* op, char* name, size_t cap);

@@ -255,3 +255,41 @@ def test_train_steps_are_bitwise_reproducible(name, B, S):
         assert torch.equal(engs[0].G, engs[1].G), step
         assert torch.equal(engs[0].P, engs[1].P), step
     assert torch.equal(engs[0].RB, engs[1].RB)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,B,S', [('inception_v3', 6, 299), ('resnet18', 8, 224)])
+def test_hipgraph_replay_equals_plain_launches(name, B, S):
+    """BASELINE config 4 asks for hipGraph-captured batches: the captured programs (eval forward; train forward + loss +
+    backward, all lanes with their fork / wait / join edges) must replay to the same bits as the plain launch lists."""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    engs = []
+    for use_graph in (False, True):
+        eng = Engine(graph.build(name, 5, pretrained=False), device=0, max_batch=B)
+        eng.graph_eval = eng.graph_train = use_graph
+        eng.init_weights(seed=77)
+        eng.dropout_seed = 3
+        engs.append(eng)
+    g = torch.Generator().manual_seed(6)
+    for step in range(3):
+        x = torch.rand(B, 3, S, S, generator=g)
+        y = torch.randint(0, 5, (B,), generator=g)
+        for eng in engs:
+            eng.load_input_nchw(x.cuda())
+            eng.target[:B].copy_(y)
+            eng.train_step(B)
+        torch.cuda.synchronize()
+        assert torch.equal(engs[0].loss, engs[1].loss), step
+        assert torch.equal(engs[0].G, engs[1].G), step
+        assert torch.equal(engs[0].P, engs[1].P), step
+    assert len(engs[1].plan(B).graphs) == 1 and not engs[0].plan(B).graphs
+    outs = []
+    for eng in engs:
+        for _ in range(2):                       # second pass replays the captured eval graph
+            eng.load_input_nchw(x.cuda())
+            pl = eng.forward_eval(B)
+        torch.cuda.synchronize()
+        outs.append([h for h in eng.heads if not h.aux][0].logits[:B].clone())
+    assert torch.equal(outs[0], outs[1])
+    assert 'fwd_eval' in engs[1].plan(B).graphs
