@@ -458,15 +458,22 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
     }
 }
 
-int pick_nt(int K, int maxnt = 6) {
-    static int force = -1;
+// N-tile choice.  Per-block time ~ (BN + 48) (measured round 1: the 48 stands for the pixel tile's load + the fixed parts),
+// so without other constraints the widest tile that wastes no columns wins.  IFCBK_CONV_MQ=1 also counts ROUNDS: the chip
+// holds 512 blocks (2 per CU); a 578-block grid (every 17x17 layer with K <= 192 at batch 256) runs a second, nearly empty
+// round, and narrower tiles (more, shorter blocks) can finish sooner.
+int pick_nt(int K, int maxnt, int M, int bm) {
+    static int force = -1, mq = -1;
     if (force < 0) { const char* e = getenv("IFCBK_CONV_NT"); force = e ? atoi(e) : 0; }
+    if (mq < 0) { const char* e = getenv("IFCBK_CONV_MQ"); mq = e ? atoi(e) : 0; }
     if (force > 0 && force <= maxnt) return force;
     int best = 1;
     long bestc = -1;
+    const long tilesM = M > 0 && mq ? cdiv(M, bm) : 0;
     for (int nt = 1; nt <= maxnt; ++nt) {
         int bn = 32 * nt;
         long c = (long)cdiv(K, bn) * (bn + 48);
+        if (tilesM) c = cdiv(tilesM * cdiv(K, bn), 512) * (bn + 48);
         if (bestc < 0 || c < bestc || (c == bestc && nt > best)) { bestc = c; best = nt; }
     }
     return best;
@@ -509,7 +516,7 @@ void launch(const ConvArgs& a, hipStream_t st) {
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;
     int wm = f32 ? 2 : pick_wm(a.M, a.K);
-    int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6));
+    int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6), a.M, 64 * wm);
     a.tilesN = cdiv(a.K, 32 * nt);
     if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
     if (f32) {
@@ -543,7 +550,7 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
 
 }  // namespace
 
-int ifcbk_conv_fwd_nt(int K) { return pick_nt(K, pick_wm(0, K) == 4 ? 5 : 6); }
+int ifcbk_conv_fwd_nt(int K, int M) { return pick_nt(K, pick_wm(M, K) == 4 ? 5 : 6, M, 64 * pick_wm(M, K)); }
 
 int ifcbk_conv_fwd_wm(int M, int K) { return pick_wm(M, K); }
 

@@ -314,7 +314,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             if (ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]))
                 snprintf(name, cap, "conv_rows3x3<%d, %d>", d.C, d.K);
             else
-            snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K), wm, wm == 4 ? 3 : 2);
+            snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q), wm, wm == 4 ? 3 : 2);
             break;
         }
         case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
@@ -327,7 +327,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
-                snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C), wm, wm == 4 ? 3 : 2, classes ? 2 : (s2 ? 1 : 0));
+                snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2, classes ? 2 : (s2 ? 1 : 0));
             }
             break;
         }
