@@ -31,7 +31,8 @@ def _loss(out, y):
     return F.cross_entropy(out, y)
 
 
-@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224)])
+@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224), ('resnet50', 3, 4, 224),
+                                         ('resnet34', 5, 3, 224)])
 def test_train_step_local_parity(name, nc, B, S):
     hip, ora = _pair(name, nc, B)
     x = torch.rand(B, 3, S, S)
@@ -63,7 +64,7 @@ def test_train_step_local_parity(name, nc, B, S):
             assert int(b.item()) == 1
 
 
-@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224)])
+@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224), ('resnet50', 3, 4, 224)])
 def test_eval_forward_end_to_end(name, nc, B, S):
     hip, ora = _pair(name, nc, B)
     x = torch.rand(B, 3, S, S)
@@ -163,7 +164,7 @@ def _pair32(name, nc, B, seed=0):
     return hip, ora
 
 
-@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224)])
+@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224), ('resnet50', 3, 4, 224)])
 def test_fp32_mode_meets_the_north_star_tolerance(name, nc, B, S):
     """fp32 storage + v_mfma_f32_16x16x4_f32: class logits within 1e-3 rel of the reference's fp32 CPU arithmetic
     (BASELINE.json north_star) in train AND eval mode and every plan node within 2e-5.  Two train steps, each
