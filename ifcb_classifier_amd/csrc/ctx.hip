@@ -327,7 +327,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
-                snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2, classes ? 2 : (s2 ? 1 : 0));
+                snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2,
+                         o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : classes ? 2 : (s2 ? 1 : 0));
             }
             break;
         }
