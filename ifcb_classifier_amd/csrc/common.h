@@ -149,6 +149,7 @@ int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int 
                            int pad_w, const void* x, const void* w, void* y, float* part, const float* scale,
                            const float* shift, int relu, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K, int M);
+bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg);     // the persistent warp-specialised kernel serves this GEMM shape
 int ifcbk_conv_fwd_wm(int M, int K);
 void ifcbk_conv_wgrad_shape(const ifcbk_conv_desc* d, int* mt, int* cols);
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Bijective remap of the linear

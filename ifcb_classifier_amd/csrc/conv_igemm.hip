@@ -458,6 +458,229 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- persistent, warp-specialised variant
+// One 512-thread block per CU walks over tiles (tile = block + r * grid).  Waves 4-7 ("producers") only run the LDS-DMA
+// gather of both operand tiles, two k-steps ahead in a 3-stage ring, and simply keep going into the NEXT tile's first
+// k-steps while waves 0-3 ("consumers", the 2x2 MFMA waves of conv_igemm) write the finished tile out -- no prologue
+// latency after the first tile, no address arithmetic and no DMA issue stalls on the MFMA waves.  One s_barrier per
+// k-step is the whole protocol: producers wait (counted vmcnt) until their pieces of step s have landed, everybody
+// meets, producers then refill the stage the consumers finished one step earlier.  Both roles execute exactly
+// tiles * nk barriers.  The consumers' epilogue goes from registers straight to memory (no LDS: the ring belongs to the
+// producers, and gfx950 has no partial-workgroup barrier for a C tile): a lane holds 4 consecutive channels of a pixel
+// per 16x16 tile (8-byte stores, 192-byte runs per pixel that L2 merges), the BatchNorm sums are reduced over the 16
+// pixel lanes with cross-lane adds and every consumer wave writes its own partial row (2 rows per 128-pixel tile).
+// Serves: forward / stride-1 first-writer input gradients in bf16 without residual (MODE 0 of conv_igemm).
+template <int NT>
+__global__ __launch_bounds__(512) void conv_ws(ConvArgs a, int total_tiles) {
+    typedef bf16_t T;
+    constexpr int ES = 2, CE = 8, BK = 64, BM = 128, BN = 32 * NT, NSTAGE = 3;
+    constexpr int STAGE = (BM + BN) * BK;              // elements per ring stage
+    constexpr int G = 4 + NT;                          // LDS-DMA instructions per producer wave per k-step
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE * ES];
+    T* sStage = reinterpret_cast<T*>(smem);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b0 = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int ngrid = (int)gridDim.x;
+    const int ntl = (total_tiles - b0 + ngrid - 1) / ngrid;          // tiles of this block (grid <= total_tiles: >= 1)
+    const int nk = (a.Kg + BK - 1) / BK;
+    const int total_steps = ntl * nk;
+
+    if (wave >= 4) {
+        // ================================================================ producers
+        const int p = wave - 4;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;
+        const int lrow8 = lane >> 3;
+        const int csrc = (lane & 7) ^ lrow8;
+        const bool plain = a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+        const bool ktail_ok = (nk - 1) * BK + csrc * CE < a.Kg;
+        const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
+        // per-tile gather state
+        int off0[4], bh[4], bw[4];
+        unsigned va[4], woff[NT];
+        int kc = 0, kr = 0, ks = 0, tapoff = 0, kt_issue = 0, r_issue = 0;
+#define WS_SETUP_TILE(tile)                                                                                   \
+        {                                                                                                     \
+            const int mtile_ = (tile) / a.tilesN, ntile_ = (tile) - mtile_ * a.tilesN;                        \
+            const int m0_ = mtile_ * BM, n0_ = ntile_ * BN;                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+                int m = m0_ + (p * 4 + j) * 8 + lrow8;                                                        \
+                bool rv = m < a.M;                                                                            \
+                int mm = rv ? m : 0;                                                                          \
+                int n = (int)fdiv((uint32_t)mm, a.fPQ);                                                       \
+                int rem = mm - n * a.PQ;                                                                      \
+                int pp = (int)fdiv((uint32_t)rem, a.fQ);                                                      \
+                int q = rem - pp * a.Q;                                                                       \
+                bh[j] = rv ? pp * a.ostr_h + a.base_h : -(1 << 24);                                           \
+                bw[j] = q * a.ostr_w + a.base_w;                                                              \
+                off0[j] = ((n * a.H + bh[j]) * a.W + bw[j]) * a.ldx;                                          \
+                va[j] = bh[j] >= 0 ? (unsigned)(off0[j] + csrc * CE) * (unsigned)ES : OOB;                    \
+            }                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                  \
+                int n = n0_ + (j * 4 + p) * 8 + lrow8;                                                        \
+                woff[j] = n < a.K ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;                    \
+            }                                                                                                 \
+            kc = csrc * CE; kr = 0; ks = 0;                                                                   \
+            while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }                               \
+            tapoff = (kr * a.W + ks) * a.ldx + kc;                                                            \
+        }
+        // issue the next k-step in program order (tile r_issue, step kt_issue) into ring stage `stage`: exactly G instructions
+#define WS_ISSUE(stage)                                                                                       \
+        {                                                                                                     \
+            if (kt_issue == 0) WS_SETUP_TILE(b0 + r_issue * ngrid)                                            \
+            T* dstA = sStage + (stage) * STAGE;                                                               \
+            T* dstB = dstA + BM * BK;                                                                         \
+            if (plain) {                                                                                      \
+                const bool cut = kt_issue == nk - 1 && !ktail_ok;                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+                    lds_dma16(rsA, (lptr_t)(dstA + (p * 4 + j) * 8 * BK), cut ? OOB : va[j], kt_issue * 128); \
+            } else {                                                                                          \
+                const bool kvalid = kr < a.R;                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+                    int hr = bh[j] + kr, wr = bw[j] + ks;                                                     \
+                    bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;          \
+                    unsigned voff = v ? (unsigned)(off0[j] + tapoff) * (unsigned)ES : OOB;                    \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dstA + (p * 4 + j) * 8 * BK), 16, voff, 0, 0, 0); \
+                }                                                                                             \
+                kc += BK;                                                                                     \
+                tapoff += BK;                                                                                 \
+                while (kc >= a.C) {                                                                           \
+                    kc -= a.C;                                                                                \
+                    tapoff += a.ldx - a.C;                                                                    \
+                    if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                           \
+                }                                                                                             \
+            }                                                                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                lds_dma16(rsB, (lptr_t)(dstB + (j * 4 + p) * 8 * BK), woff[j], kt_issue * 128);               \
+            if (++kt_issue == nk) { kt_issue = 0; ++r_issue; }                                                \
+        }
+        if (total_steps > 0) WS_ISSUE(0)
+        if (total_steps > 1) WS_ISSUE(1)
+        int istage = 2;
+        for (int s = 0; s < total_steps; ++s) {
+            if (s + 1 < total_steps) wait_vmcnt<G>();       // step s has landed; step s+1 may still be in flight
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                   // consumers are done with step s-1: its stage is free
+            if (s + 2 < total_steps) WS_ISSUE(istage)
+            istage = istage == 2 ? 0 : istage + 1;
+        }
+#undef WS_ISSUE
+#undef WS_SETUP_TILE
+        return;
+    }
+
+    // ==================================================================== consumers
+    typedef bf16x8_t frag_t;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const T* fA[2];
+    const T* fB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) * CE;
+        fA[kk] = sStage + (wm * 64 + frow) * BK + ph;
+        fB[kk] = sStage + BM * BK + (wn * (NT * 16) + frow) * BK + ph;
+    }
+    int stage = 0;
+    for (int r = 0; r < ntl; ++r) {
+        const int tile = b0 + r * ngrid;
+        const int mtile = tile / a.tilesN, ntile = tile - mtile * a.tilesN;
+        const int m0 = mtile * BM, n0 = ntile * BN;
+        f32x4_t acc[NT][4];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            __builtin_amdgcn_s_barrier();                   // every producer's share of this step is in LDS
+            const int soff = stage * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                frag_t fa[4], fb[NT];
+                const T* pa = fA[kk] + soff;
+                const T* pb = fB[kk] + soff;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const frag_t*>(pa + mt * 16 * BK);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const frag_t*>(pb + nt * 16 * BK);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        Mma<T>::run(fb[nt], fa[mt], acc[nt][mt]);
+            }
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        }
+        // ---- epilogue, registers -> memory
+        const int g = lane >> 4;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const int ncol = n0 + wn * (NT * 16) + 4 * g;                 // + nt*16: this lane's 4 channels of tile nt
+        bool mv[4];
+        T* row[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + frow;
+            mv[mt] = m < a.M;
+            row[mt] = (T*)a.y + (size_t)(mv[mt] ? m : 0) * a.ldy + ncol;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool nv = ncol + nt * 16 < a.K;                     // K is a multiple of 8: the 4 channels are valid together
+            float sc[4], sh[4];
+            if (a.ep_scale) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sc[j] = nv ? a.ep_scale[ncol + nt * 16 + j] : 0.f;
+                    sh[j] = nv ? a.ep_shift[ncol + nt * 16 + j] : 0.f;
+                }
+            }
+            f32x2_t s1[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}}, s2[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4_t v = acc[nt][mt];
+                if (a.ep_scale) {
+                    // the affine acts on the conv output AS STORED in training (rounded to bf16), like conv_igemm's epilogue
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = bf2f(f2bf(v[j])) * sc[j] + sh[j];
+                        if (a.ep_relu) v[j] = fmaxf(v[j], 0.f);
+                    }
+                }
+                uint2 u;
+                u.x = pack2bf(v[0], v[1]);
+                u.y = pack2bf(v[2], v[3]);
+                if (mv[mt] && nv) *reinterpret_cast<uint2*>(row[mt] + nt * 16) = u;
+                // statistics of the ROUNDED values (what bn_apply reads back); rows past M / columns past K are zeros
+                const f32x2_t lo = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+                const f32x2_t hi = {__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+                s1[0] += lo; s1[1] += hi;
+                s2[0] += lo * lo; s2[1] += hi * hi;
+            }
+            if (a.part) {
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            s1[h][j] += __shfl_xor(s1[h][j], off);
+                            s2[h][j] += __shfl_xor(s2[h][j], off);
+                        }
+                if (frow == 0 && nv) {
+                    float* prow = a.part + ((size_t)(mtile * 2 + wm) * 2) * a.K + ncol + nt * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        prow[j] = s1[j >> 1][j & 1];
+                        prow[a.K + j] = s2[j >> 1][j & 1];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // N-tile choice.  Per-block time ~ (BN + 48) (measured round 1: the 48 stands for the pixel tile's load + the fixed parts),
 // so without other constraints the widest tile that wastes no columns wins.  IFCBK_CONV_MQ=1 also counts ROUNDS: the chip
 // holds 512 blocks (2 per CU); a 578-block grid (every 17x17 layer with K <= 192 at batch 256) runs a second, nearly empty
@@ -513,12 +736,65 @@ void launch(const ConvArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 0>), grid, block, 0, st, a);
 }
 
+// persistent warp-specialised kernel.  Measured per layer (batch 256, one lane): +25-40 % where a CU gets at most two
+// tiles (every 8x8 layer: 705 -> 987 TF/s on Mixed_7b/7c 3x3, 500 -> 630 on the 1x3 / 3x1), neutral on the 578-tile
+// 17x17 layers, 10-25 % SLOWER where a CU walks through many short tiles (35x35 layers, the fused 17x17 1x1s): there
+// the consumers' epilogue is exposed, while conv_igemm's partner block covers it.  Hence: grids of at most
+// IFCBK_CONV_WS_TILES tiles (default 2 per CU) with at least IFCBK_CONV_WS k-steps (default 4; 0 = never).
+int ws_min_steps() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IFCBK_CONV_WS"); v = e ? atoi(e) : 4; }
+    return v;
+}
+int num_cus();
+int ws_max_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IFCBK_CONV_WS_TILES"); v = e ? atoi(e) : 2 * num_cus(); }
+    return v;
+}
+// M, K, Kg of the GEMM view (pixels, output channels, reduction length)
+bool ws_shape_ok(int dtype, int M, int K, int Kg) {
+    const int ms = ws_min_steps();
+    if (ms <= 0 || dtype != IFCBK_BF16 || pick_wm(M, K) != 2 || cdiv(Kg, 64) < ms) return false;
+    const int nt = pick_nt(K, 6, M, 128);
+    return (int64_t)cdiv(M, 128) * cdiv(K, 32 * nt) <= ws_max_tiles();
+}
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int NT>
+void launch_ws(const ConvArgs& a, hipStream_t st) {
+    const int total = cdiv(a.M, 128) * a.tilesN;
+    const int grid = total < num_cus() ? total : num_cus();
+    hipLaunchKernelGGL((conv_ws<NT>), dim3((unsigned)grid), dim3(512), 0, st, a, total);
+}
+
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;
     int wm = f32 ? 2 : pick_wm(a.M, a.K);
     int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6), a.M, 64 * wm);
     a.tilesN = cdiv(a.K, 32 * nt);
     if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
+    if (ws_shape_ok(dtype, a.M, a.K, a.Kg) && !a.bs_raw && !a.wKg && !(a.ish | a.isw) && !a.accumulate && !a.ep_res) {
+        switch (nt) {
+            case 1: launch_ws<1>(a, st); break;
+            case 2: launch_ws<2>(a, st); break;
+            case 3: launch_ws<3>(a, st); break;
+            case 4: launch_ws<4>(a, st); break;
+            case 5: launch_ws<5>(a, st); break;
+            default: launch_ws<6>(a, st); break;
+        }
+        IFCBK_LAUNCH_CHECK(ctx, "conv_ws");
+        return 0;
+    }
     if (f32) {
         switch (nt) {
             case 1: launch<float, 1, 2, 2>(a, st); break;
@@ -554,6 +830,8 @@ int ifcbk_conv_fwd_nt(int K, int M) { return pick_nt(K, pick_wm(M, K) == 4 ? 5 :
 
 int ifcbk_conv_fwd_wm(int M, int K) { return pick_wm(M, K); }
 
+bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg) { return ws_shape_ok(dtype, M, K, Kg); }
+
 static bool fwd_rows(const ifcbk_conv_desc* d) {
     return ifcbk_conv_rows_ok(d->dtype, d->C, d->K, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->Q);
 }
@@ -561,6 +839,7 @@ static bool fwd_rows(const ifcbk_conv_desc* d) {
 extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     if (fwd_rows(d)) return ifcbk_conv_rows_blocks(d->N, d->P);
     int M = d->N * d->P * d->Q;
+    if (ws_shape_ok(d->dtype, M, d->K, d->R * d->S * d->C)) return 2 * cdiv(M, 128);      // conv_ws: one partial row per consumer wave row
     return cdiv(M, 64 * pick_wm(M, d->K));
 }
 

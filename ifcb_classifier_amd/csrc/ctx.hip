@@ -313,6 +313,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
             if (ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]))
                 snprintf(name, cap, "conv_rows3x3<%d, %d>", d.C, d.K);
+            else if (!(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]) && ifcbk_conv_ws_shape(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C))
+                snprintf(name, cap, "conv_ws<%d>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q));
             else
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q), wm, wm == 4 ? 3 : 2);
             break;
@@ -326,6 +328,10 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                     break;
                 }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
+                if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && !s2 && ifcbk_conv_ws_shape(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K)) {
+                    snprintf(name, cap, "conv_ws<%d>", ifcbk_conv_fwd_nt(d.C, d.N * d.H * d.W));
+                    break;
+                }
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
                 snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2,
                          o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : classes ? 2 : (s2 ? 1 : 0));
