@@ -296,6 +296,10 @@ def main():
                                if use_ev else 'N > 1: rank 0, untimed survey pass (3 local steps, every op bracketed, one lane)',
                                'isolated_tflops': round(survey[dom]['flops'] / (survey[dom]['ms'] * 1e-3) / 1e12, 2),
                                'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5)}
+            if dom.startswith('conv_wgrad'):
+                # one weight-gradient op = the split-K MFMA kernel + its fixed-order fp32 reduction (wgrad_reduce): the event
+                # bracket, avg_launch_ms and achieved cover BOTH; rocprofv3 lists them as two kernels (their averages add up)
+                out['roofline']['bracket_includes'] = 'wgrad_reduce'
             conv = {k: v for k, v in survey.items() if k.startswith('conv_')}
             call = sum(v['flops'] for v in conv.values()) / (sum(v['ms'] for v in conv.values()) * 1e-3) / 1e12
             out['conv_all'] = {'achieved_tflops': round(call, 2), 'frac': round(call / MFMA_BF16_PEAK_TFLOPS, 4),
