@@ -159,7 +159,12 @@ class Engine:
         self.dev = torch.device('cuda', device)
         torch.cuda.set_device(self.dev)
         self.ctx = _lib.Context(device)
-        self.max_batch = int(max_batch)
+        # the kernels address every tensor through a 32-bit buffer descriptor (2 GiB window): the largest per-image tensor
+        # (inception_v3: 147x147x64 bf16 = 2.77 MB) bounds the images one launch can take (776 in bf16, 388 in fp32)
+        self.requested_batch = int(max_batch)
+        per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
+        self.window_batch = max(1, ((1 << 31) - 1) // per_img)
+        self.max_batch = min(int(max_batch), self.window_batch)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.packed = False

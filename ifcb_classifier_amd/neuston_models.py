@@ -98,7 +98,13 @@ class HipBackbone(nn.Module):
     def forward(self, x):
         eng = self.engine
         if x.shape[0] > eng.max_batch:
-            raise RuntimeError('batch %d > max_batch %d (construct with a larger max_batch)' % (x.shape[0], eng.max_batch))
+            if self.training or x.shape[0] > eng.requested_batch:
+                why = ('the 2 GiB buffer-descriptor window holds %d images of this network per launch, and BatchNorm batch '
+                       'statistics cannot be taken over chunks: use a smaller --batch per GPU (more GPUs)' % eng.window_batch
+                       if x.shape[0] <= eng.requested_batch else 'construct with a larger max_batch')
+                raise RuntimeError('batch %d > capacity %d: %s' % (x.shape[0], eng.max_batch, why))
+            # eval mode: samples are independent, so a batch beyond the descriptor window runs as chunks (same results)
+            return torch.cat([self.forward(c) for c in x.split(eng.max_batch)], 0)
         N = eng.load_input_nchw(x)
         if self.training:
             if torch.is_grad_enabled():

@@ -237,6 +237,12 @@ def do_training(args):
     trainer = Trainer(args.emax, args.emin, args.estop, args.outdir, callbacks)
     hp = argparse.Namespace(**{k: v for k, v in vars(args).items()})
     classifier = NeustonModel(hp, device=int(os.environ.get('LOCAL_RANK', 0)), max_batch=args.batch_size)
+    eng = classifier.model.engine
+    if eng.max_batch < args.batch_size:
+        # --batch is per GPU as upstream (neuston_net.py:102); BatchNorm statistics are per step, so a step cannot be chunked
+        raise ValueError('--batch %d: one launch addresses each tensor through a 2 GiB buffer descriptor, which holds %d images '
+                         'of %s; use --batch <= %d per GPU (and more GPUs for a larger global batch)'
+                         % (args.batch_size, eng.window_batch, args.MODEL, eng.window_batch))
     trainer.fit(classifier, training_loader, validation_loader)
     if rank != 0:
         return
@@ -267,6 +273,11 @@ def do_run(args):
     classifier = NeustonModel.load_from_checkpoint(args.MODEL, device=int(os.environ.get('LOCAL_RANK', 0)),
                                                    max_batch=args.batch_size)
     seed_everything(classifier.hparams.seed)
+    if classifier.model.engine.max_batch < args.batch_size:
+        # results are per image: a batch beyond the 2 GiB buffer-descriptor window is only a smaller launch, not a different answer
+        print('--batch %d exceeds the %d images one launch can address; running batches of %d'
+              % (args.batch_size, classifier.model.engine.window_batch, classifier.model.engine.max_batch))
+        args.batch_size = classifier.model.engine.max_batch
     if os.path.isdir(args.SRC) and not args.SRC.endswith(os.sep):
         args.SRC = args.SRC + os.sep
     if not args.outfile:

@@ -3,7 +3,9 @@ sys.path.insert(0, '.')
 from ifcb_classifier_amd import graph
 from ifcb_classifier_amd.engine import Engine
 import bench
-for B in (256, 512, 1024):
+# one launch addresses each tensor through a 2 GiB buffer descriptor: 776 inception_v3 images at most (engine.window_batch);
+# the RUN loop feeds larger --batch values as chunks of that size
+for B in (256, 512, 768):
     eng = Engine(graph.build('inception_v3', 100, pretrained=False), device=0, max_batch=B)
     eng.init_weights(seed=1)
     rois, _ = bench.synth_rois(B, 1, eng.dev)

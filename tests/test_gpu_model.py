@@ -294,3 +294,27 @@ def test_hipgraph_replay_equals_plain_launches(name, B, S):
         outs.append([h for h in eng.heads if not h.aux][0].logits[:B].clone())
     assert torch.equal(outs[0], outs[1])
     assert 'fwd_eval' in engs[1].plan(B).graphs
+
+
+@pytest.mark.gpu
+def test_batch_beyond_the_descriptor_window_is_chunked_in_eval_and_refused_in_training():
+    """every tensor is addressed through a 32-bit buffer descriptor: the engine caps its capacity at the images that fit
+    2 GiB (776 for inception_v3 in bf16); an eval batch beyond it runs as chunks with identical results, a training
+    batch is refused (BatchNorm statistics are per step)."""
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    m = get_namebrand_model('resnet18', 3, max_batch=12)
+    eng = m.engine
+    assert eng.window_batch == ((1 << 31) - 1) // (112 * 112 * 64 * 2) and eng.max_batch == 12
+    eng.window_batch, eng.max_batch = 5, 5              # pretend the window holds 5 images
+    x = torch.rand(12, 3, 224, 224).cuda()
+    m.eval()
+    with torch.no_grad():
+        whole = m(x)
+        parts = torch.cat([m(x[:5]), m(x[5:10]), m(x[10:])], 0)
+    assert whole.shape == (12, 3) and torch.equal(whole, parts)
+    m.train()
+    with pytest.raises(RuntimeError, match='BatchNorm batch statistics'):
+        m(x)
+    with pytest.raises(RuntimeError, match='larger max_batch'):
+        m.eval()
+        m(torch.rand(13, 3, 224, 224).cuda())
