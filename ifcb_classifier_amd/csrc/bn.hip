@@ -93,6 +93,62 @@ __global__ void bn_eval_scale_kernel(int C, const float* gamma, const float* bet
     shift[ch] = beta[ch] - rmean[ch] * sc;
 }
 
+// ---------------------------------------------------------------- statistics of a stored tensor
+// partial (sum x, sum x^2) per 1024-row tile; block: 8 chunks x 32 rows in flight, fixed reduction order
+constexpr int STAT_ROWS = 1024;
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* x, int ldx, float* part, int64_t M, int C) {
+    constexpr int E = Chunk<T>::N;
+    constexpr int CG = 8 * E;
+    __shared__ float red[4][2][CG];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cc = t & 7, r0 = t >> 3;
+    const int c = blockIdx.y * CG + cc * E;
+    const int64_t mbeg = (int64_t)blockIdx.x * STAT_ROWS;
+    const int64_t mend = mbeg + STAT_ROWS < M ? mbeg + STAT_ROWS : M;
+    float s1[E], s2[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) s1[j] = s2[j] = 0.f;
+    if (c < C) {
+        int64_t m = mbeg + r0;
+        for (; m + 96 < mend; m += 128) {          // four rows per trip: independent loads, fixed add order
+            float f[4][E];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Chunk<T>::load(x + (m + 32 * u) * ldx + c, f[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < E; ++j) { s1[j] += f[u][j]; s2[j] += f[u][j] * f[u][j]; }
+        }
+        for (; m < mend; m += 32) {
+            float f[E];
+            Chunk<T>::load(x + m * ldx + c, f);
+#pragma unroll
+            for (int j = 0; j < E; ++j) { s1[j] += f[j]; s2[j] += f[j] * f[j]; }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            s1[j] += __shfl_xor(s1[j], off);
+            s2[j] += __shfl_xor(s2[j], off);
+        }
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            red[wave][0][cc * E + j] = s1[j];
+            red[wave][1][cc * E + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * CG) {
+        int which = t / CG, n = t - which * CG;
+        int ch = blockIdx.y * CG + n;
+        if (ch < C) part[((size_t)blockIdx.x * 2 + which) * C + ch] = (red[0][which][n] + red[1][which][n]) + (red[2][which][n] + red[3][which][n]);
+    }
+}
+
 // ---------------------------------------------------------------- apply
 // per-channel coefficients are staged once per block in LDS (8 chunks per thread amortise it): the payload loads are
 // the only global traffic in the loop
@@ -635,6 +691,20 @@ extern "C" int ifcbk_bn_finalize_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, cons
                            (const float*)running_mean, (const float*)running_var, scale, shift, d->eps);
     }
     IFCBK_LAUNCH_CHECK(ctx, "bn_finalize");
+    return 0;
+}
+
+extern "C" int ifcbk_bn_stats_rows(int64_t M) { return (int)((M + STAT_ROWS - 1) / STAT_ROWS); }
+
+extern "C" int ifcbk_bn_stats(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, float* part, void* stream) {
+    if (!d || !x || !part) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_stats: null operand");
+    if (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "bn_stats: dtype must be bf16 or f32");
+    const int e = dtype_chunk(d->dtype);
+    if (d->C % e || d->ldx % e || d->M <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_stats: C=%d ldx=%d must be multiples of %d, M > 0", d->C, d->ldx, e);
+    const dim3 grid((unsigned)ifcbk_bn_stats_rows(d->M), (unsigned)cdiv(d->C, 8 * e));
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, d->ldx, part, d->M, d->C);
+    else hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, d->ldx, part, d->M, d->C);
+    IFCBK_LAUNCH_CHECK(ctx, "bn_stats");
     return 0;
 }
 

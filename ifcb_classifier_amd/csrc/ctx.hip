@@ -96,6 +96,7 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_bn_bwd_partials(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
                                          (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], p[8], (int)o->i[2],
                                          (float*)p[9], (float*)p[10], pacc, st);
+        case IFCBK_OP_BN_STATS: return ifcbk_bn_stats(c, &o->u.bn, p[0], (float*)p[1], st);
         case IFCBK_OP_BN_APPLY_MAXPOOL:
             return ifcbk_bn_apply_maxpool(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (int)o->i[0], p[3], (uint8_t*)p[4], st);
         case IFCBK_OP_BN_BWD_MAXPOOL:
@@ -352,6 +353,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_BN_APPLY_MAXPOOL: snprintf(name, cap, "bn_apply_maxpool_kernel"); break;
         case IFCBK_OP_BN_BWD_MAXPOOL: snprintf(name, cap, "bn_bwd(maxpool)"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;
+        case IFCBK_OP_BN_STATS: snprintf(name, cap, "bn_stats_kernel"); break;
         case IFCBK_OP_MAXPOOL_FWD: snprintf(name, cap, "maxpool_fwd_kernel"); break;
         case IFCBK_OP_MAXPOOL_BWD: snprintf(name, cap, "maxpool_bwd_kernel"); break;
         case IFCBK_OP_AVGPOOL_FWD: snprintf(name, cap, "avgpool_fwd_kernel"); break;
@@ -378,6 +380,7 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             break;
         }
         case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;
+        case IFCBK_OP_BN_STATS: by = (double)o->u.bn.M * o->u.bn.C * 2; break;
         case IFCBK_OP_BN_BWD: by = (double)o->u.bn.M * o->u.bn.C * (2.0 * (o->u.bn.relu ? 6 : 4) + 2 + (o->p[7] ? 2 : 0)); break;
         case IFCBK_OP_BN_BWD_PARTIALS: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + 2); break;      // x, dy in; dx out
         case IFCBK_OP_BN_APPLY_MAXPOOL: {

@@ -221,13 +221,40 @@ class Engine:
             pass
         self.groups = []
         bykey = {}
+        # An Inception block's pool branch is avgpool3x3(s1,p1) -> 1x1 conv -> BN -> ReLU.  Both operators are linear and the
+        # conv has no bias, so conv1x1(avgpool(x)) == avgpool(conv1x1(x)) (zero padding included: count_include_pad averages
+        # zeros, and conv1x1(0) = 0).  In TRAINING the engine runs the conv first -- as one more member of the block's
+        # sibling GEMM on x -- and pools its pf = 32..192 output channels instead of the block's 192..2048 input channels:
+        # the pool's traffic shrinks 4-10x in both directions and the branch needs no conv launches of its own.  BatchNorm
+        # then normalises the pooled tensor, whose batch statistics come from ifcbk_bn_stats.  Eval keeps the reference order.
+        self.commute_pool = os.environ.get('IFCBK_COMMUTE_POOL', '1') != '0' and self.fuse_siblings
+        nread = {}
+        for m in net.nodes:
+            for v in ((m.x, getattr(m, 'residual', None)) if m.kind == 'conv' else (m.x,)):
+                if v is not None:
+                    nread[v.buf.id] = nread.get(v.buf.id, 0) + 1
+        for n in convs:
+            n.cpool = None
+            if (self.commute_pool and n.R == 1 and n.S == 1 and n.sh == 1 and n.sw == 1 and n.ph == 0 and n.pw == 0
+                    and n.x.is_full and n.residual is None and n.relu and not n.aux and nread.get(n.x.buf.id, 0) == 1):
+                prod = [m for m in net.nodes if m.kind == 'avg' and m.y.buf.id == n.x.buf.id]
+                if (len(prod) == 1 and (prod[0].R, prod[0].S, prod[0].sh, prod[0].sw, prod[0].ph, prod[0].pw) == (3, 3, 1, 1, 1, 1)
+                        and prod[0].x.is_full and prod[0].y.is_full and not prod[0].x.buf.is_input and not prod[0].aux):
+                    n.cpool = prod[0]
         if self.fuse_siblings:
             for n in convs:
                 n.group = None
-                if (n.R == 1 and n.S == 1 and n.sh == 1 and n.sw == 1 and n.ph == 0 and n.pw == 0 and n.x.is_full
-                        and not n.x.buf.is_input and n.residual is None and n.relu):
-                    bykey.setdefault(n.x.buf.id, []).append(n)
+                src = n.cpool.x if n.cpool is not None else n.x
+                if (n.R == 1 and n.S == 1 and n.sh == 1 and n.sw == 1 and n.ph == 0 and n.pw == 0 and src.is_full
+                        and not src.buf.is_input and n.residual is None and n.relu):
+                    bykey.setdefault(src.buf.id, []).append(n)
         for members in bykey.values():
+            plain = [m for m in members if m.cpool is None]
+            if not (2 <= len(members) <= 4) or not plain:
+                for m in members:
+                    m.cpool = None                      # no sibling GEMM to join: keep the reference order
+                members = plain
+            members = plain + [m for m in members if m.cpool is not None]      # the first member launches the group's GEMMs
             if 2 <= len(members) <= 4:
                 g = Group()
                 g.members, g.x = members, members[0].x
@@ -240,6 +267,9 @@ class Engine:
         for n in convs:
             if not hasattr(n, 'group'):
                 n.group = None
+            if n.group is None:
+                n.cpool = None
+        self.absorbed_pools = {n.cpool for n in convs if n.cpool is not None}
         soff = 0
         stoff = 0
         done = set()
@@ -312,7 +342,7 @@ class Engine:
         bf = self.tdtype
         self.act = {}
         self.grad = {}
-        grouped_raw = {m.raw.id: m for g in self.groups for m in g.members}
+        grouped_raw = {m.raw.id: m for g in self.groups for m in g.members if m.cpool is None}
         for b in net.bufs:
             if b.id in grouped_raw:
                 continue                              # lives inside the group's merged raw tensor
@@ -320,7 +350,9 @@ class Engine:
         for g in self.groups:
             g.raw = torch.zeros(N, g.x.H, g.x.W, g.Ktot, dtype=bf, device=dev)
             for m in g.members:
-                self.act[m.raw.id] = g.raw[..., m.koff:m.koff + m.K]        # strided view (tests / debugging)
+                if m.cpool is None:
+                    self.act[m.raw.id] = g.raw[..., m.koff:m.koff + m.K]        # strided view (tests / debugging)
+                # a commuted pool branch: its slice of g.raw is the UNPOOLED conv output, m.raw (own buffer) the pooled one
         need_grad = set()
         for n in net.nodes:
             if getattr(n, 'kind', '') == 'conv':
@@ -412,9 +444,13 @@ class Engine:
 
     def _raw_ptr(self, n):
         """(pointer, pixel stride) of a conv's raw output -- a channel slice of the merged tensor for fused siblings"""
-        if n.group is not None:
+        if n.group is not None and n.cpool is None:
             return _vp(n.group.raw, self.esize * n.koff), n.group.Ktot
         return _vp(self.act[n.raw.id]), n.K
+
+    def _pre_ptr(self, n):
+        """a commuted pool branch's unpooled 1x1-conv output: its channel slice of the sibling GEMM's merged tensor"""
+        return _vp(n.group.raw, self.esize * n.koff), n.group.Ktot
 
     # ------------------------------------------------------------------ programs
     def plan(self, N):
@@ -502,7 +538,11 @@ class Engine:
             return ('g', v.buf.id, v.coff, v.coff + v.C)
 
         def rraw(m):
-            return ('gr', id(m.group), m.koff, m.koff + m.K) if m.group is not None else ('r', m.raw.id, 0, m.K)
+            if m.group is not None and m.cpool is None:
+                return ('gr', id(m.group), m.koff, m.koff + m.K)
+            return ('r', m.raw.id, 0, m.K)
+
+        absorbed = self.absorbed_pools
 
         def rdg(m):
             return ('dg', id(m.group), m.koff, m.koff + m.K)
@@ -554,6 +594,25 @@ class Engine:
                             mbk = m.bn_key
                             mraw, mld = self._raw_ptr(m)
                             mbnd = BnDesc(M, m.K, mld, m.y.buf.C, 1, self.cdtype, m.eps, 0.1)
+                            if m.cpool is not None:
+                                # commuted pool branch: pool the conv's slice of the merged tensor, then BatchNorm the pooled tensor
+                                Lm, pn = lane_of[m], m.cpool
+                                pre, ldpre = self._pre_ptr(m)
+                                ppd = PoolDesc(N, pn.x.H, pn.x.W, m.K, ldpre, 3, 3, 1, 1, 1, 1, pn.P, pn.Q, mld, self.cdtype)
+                                rpre, rr2 = ('gr', id(g), m.koff, m.koff + m.K), ('r', m.raw.id, 0, m.K)
+                                lst.add(_lib.OP_AVGPOOL_FWD, pn.name + '(' + m.name + ')', p=(pre, mraw), pool=ppd, lane=Lm,
+                                        reads=[rpre], writes=[rr2])
+                                lst.add(_lib.OP_BN_STATS, m.name, p=(mraw, _vp(self.bn_part[Lm])), bn=mbnd, lane=Lm,
+                                        reads=[rr2], writes=[rbp(Lm)])
+                                lst.add(_lib.OP_BN_FINALIZE, m.name,
+                                        p=(_vp(self.bn_part[Lm]), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
+                                           _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
+                                           self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
+                                        i=(self.ctx.lib.ifcbk_bn_stats_rows(M), m.K), bn=mbnd, lane=Lm, reads=[rbp(Lm)], writes=[rst(m)])
+                                lst.add(_lib.OP_BN_APPLY, m.name,
+                                        p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd,
+                                        lane=Lm, reads=[rr2, rst(m)], writes=[ra(m.y)])
+                                continue
                             lst.add(_lib.OP_BN_FINALIZE, m.name,
                                     p=(_vp(self.bn_part[0], 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
                                        _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
@@ -591,7 +650,7 @@ class Engine:
                 pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(ckey), wk, wT if needs_dgrad else None), i=(n.wT_ld,), conv=d)
                 # ---- backward of this node
                 di = L * 2 + (k & 1) if self.wgrad_side_lane else L
-                draw = _vp(self.draw[di]) if g is None else _vp(self.draw_group, self.esize * n.koff)
+                draw = _vp(self.draw[di]) if (g is None or n.cpool is not None) else _vp(self.draw_group, self.esize * n.koff)
                 dres, lddres, dres_acc = None, 0, 0
                 # (flags resolved later, in reverse order) -> store a closure
                 bwd_groups.append(('conv', n, d, bnd, draw, wT, needs_dgrad, di))
@@ -601,6 +660,8 @@ class Engine:
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
                         continue
+                    if train and n in absorbed:
+                        continue                  # runs behind its 1x1 conv, on that conv's output (see __init__)
                     if n.kind == 'max':
                         if train and n in fused_pool_nodes:
                             continue              # done by the producing conv's bn_apply_maxpool
@@ -638,6 +699,8 @@ class Engine:
                 assert n.x.is_full
                 if n in fused_pool_nodes:
                     continue                      # gathered inside the producer's bn_bwd_maxpool
+                if n in absorbed:
+                    continue                      # its gradient reaches x through the sibling GEMM's input gradient
                 acc = acc_flag(n.x.buf)
                 if n.kind == 'max':
                     bwd.add(_lib.OP_MAXPOOL_BWD, n.name, p=(self._aptr(n.y, True), _vp(self.argmax[k]), self._aptr(n.x, True)), flags=acc, pool=pd,
@@ -655,7 +718,8 @@ class Engine:
                     dres, lddres = self._aptr(n.residual, True), n.residual.buf.C
                 grp = n.group
                 L = lane_of[n]
-                rdraw = [rdg(n)] if grp is not None else [('draw', di, 0, 1)]     # d(raw): merged-group slice or the lane's scratch
+                cp = n.cpool is not None
+                rdraw = [rdg(n)] if (grp is not None and not cp) else [('draw', di, 0, 1)]     # d(raw): merged-group slice or the lane's scratch
                 rawp, _ld = self._raw_ptr(n)
                 if n in fused_pool:
                     pn, pk = fused_pool[n]
@@ -678,9 +742,17 @@ class Engine:
                             p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
                                self._stat(n, 0), self._stat(n, 1), draw, dres, self._pptr(bkey + '.weight', 'G'),
                                self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
-                            i=(n.y.buf.C, n.K if grp is None else grp.Ktot, lddres), flags=dres_acc, bn=bnd, lane=L,
+                            i=(n.y.buf.C, n.K if (grp is None or cp) else grp.Ktot, lddres), flags=dres_acc, bn=bnd, lane=L,
                             reads=[rraw(n), ra(n.y), rg(n.y), rst(n)],
                             writes=rdraw + ([rg(n.residual)] if n.residual is not None else []))
+                if cp:
+                    # d(pooled conv output) -> d(conv output): the average pool is its own transpose; into the branch's slice of
+                    # the merged d(raw) scratch, from where the sibling GEMM's weight / input gradients pick it up
+                    pn = n.cpool
+                    ppd = PoolDesc(N, pn.x.H, pn.x.W, n.K, grp.Ktot, 3, 3, 1, 1, 1, 1, pn.P, pn.Q, n.K, self.cdtype)
+                    bwd.add(_lib.OP_AVGPOOL_BWD, pn.name + '(' + n.name + ')',
+                            p=(draw, _vp(self.draw_group, self.esize * n.koff)), flags=0, pool=ppd, lane=L,
+                            reads=rdraw, writes=[rdg(n)])
                 if grp is not None:
                     # fused siblings: every member's d(raw) lands in its slice of the merged scratch; the member that
                     # comes FIRST in forward order is the last one here and launches the single wgrad + dgrad

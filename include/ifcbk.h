@@ -218,6 +218,14 @@ int ifcbk_nhwc_to_nchw_f32(ifcbk_ctx*, const void* x, int N, int C, int H, int W
  * neuston_models.py:66-68).                                                                             */
 int ifcbk_bn_apply_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, const float* scale,
                            const float* shift, int relu, void* y, uint8_t* argmax, void* stream);
+/* Batch statistics of a tensor that no conv epilogue produced (an average pool moved BEHIND its 1x1 conv: the BatchNorm
+ * input is then the pool's output): partial sums (sum x, sum x^2 of the stored values) per 1024-row tile into
+ * part [ifcbk_bn_stats_rows(M)][2][C], to be reduced by ifcbk_bn_finalize like a conv epilogue's partials.
+ * Replaces the statistics half of [TV] BasicConv2d's nn.BatchNorm2d in training mode (reference call site
+ * neuston_models.py:66-68).                                                                                              */
+int ifcbk_bn_stats_rows(int64_t M);
+int ifcbk_bn_stats(ifcbk_ctx*, const ifcbk_bn_desc* d, const void* x, float* part, void* stream);
+
 /* ... and its backward: BN backward whose upstream gradient is maxpool_bwd(dpool, argmax), gathered on the fly
  * (neither the activation nor its gradient exists in memory).  dx: gradient of the conv output (ld lddx). */
 int ifcbk_bn_bwd_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, const void* dpool,
@@ -252,7 +260,7 @@ enum {
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
     IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
-    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS
+    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS
 };
 typedef struct {
     int32_t kind;

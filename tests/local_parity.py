@@ -22,7 +22,7 @@ def check_plan(hip, N, mask=None, verbose=False):
     P = {k: p.detach().cpu() for k, p in hip.named_parameters()}
     G = {k: p.grad.detach().cpu() for k, p in hip.named_parameters()}
     expected = {}      # buf id -> expected total gradient (NCHW fp32)
-    worst = dict(raw=0.0, y=0.0, dW=0.0, dgamma=0.0, dbeta=0.0, pool=0.0, head=0.0, dx=0.0, stats=0.0)
+    worst = dict(raw=0.0, raw_cp=0.0, y=0.0, dW=0.0, dW_cp=0.0, dgamma=0.0, dbeta=0.0, pool=0.0, head=0.0, dx=0.0, stats=0.0)
 
     def add_expected(view, g):
         assert view.is_full
@@ -36,16 +36,26 @@ def check_plan(hip, N, mask=None, verbose=False):
 
     fused = getattr(eng, 'fused_pool', {})            # conv node -> (max-pool node, index): activation never materialised
     fused_y = {}                                      # pool node -> the oracle's activation of the HIP raw output
+    absorbed = getattr(eng, 'absorbed_pools', set())    # avg pools that run BEHIND their 1x1 conv in training (engine.__init__)
     for k, n in enumerate(net.nodes):
         if n.kind == 'conv':
-            x = act(n.x)
+            cp = getattr(n, 'cpool', None)
+            if cp is not None:
+                # the engine computed avgpool(conv1x1(x)); the reference order conv1x1(avgpool(x)) is the same linear map:
+                # the oracle takes the reference order on the block input the HIP path read
+                x0 = act(cp.x)
+                x = O.pool_fwd('avg', x0, (cp.R, cp.S), (cp.sh, cp.sw), (cp.ph, cp.pw))
+            else:
+                x = act(n.x)
             if n.x.buf.is_input:
                 x = x[:, :3]
             w = P[n.conv_key + '.weight']
             gamma, beta = P[n.bn_key + '.weight'], P[n.bn_key + '.bias']
             stride, pad = (n.sh, n.sw), (n.ph, n.pw)
             raw_h = eng.act[n.raw.id][:N].float().cpu().permute(0, 3, 1, 2).contiguous()
-            upd('raw', rel(raw_h, O.conv_raw(x, w, stride, pad)), n.name)
+            # a commuted pool branch rounds to the storage type at a different place than the reference order (after the conv
+            # and after the pool, instead of after the pool and after the conv): same count of roundings, not the same bits
+            upd('raw_cp' if cp is not None else 'raw', rel(raw_h, O.conv_raw(x, w, stride, pad)), n.name)
             res = act(n.residual) if n.residual is not None else None
             y_ref, mean, var = O.bn_act_fwd(raw_h, gamma, beta, n.eps, n.relu, res)
             if n in fused:
@@ -65,12 +75,16 @@ def check_plan(hip, N, mask=None, verbose=False):
             upd('dbeta', rel(G[n.bn_key + '.bias'], db), n.name)
             need_dx = not n.x.buf.is_input
             dw, dx = O.conv_bwd(x, w, d_raw, stride, pad, need_dx)
-            upd('dW', rel(G[n.conv_key + '.weight'], dw), n.name)
-            if need_dx:
+            upd('dW_cp' if cp is not None else 'dW', rel(G[n.conv_key + '.weight'], dw), n.name)      # (same remark as raw_cp)
+            if need_dx and cp is not None:
+                add_expected(cp.x, O.pool_bwd('avg', x0, (cp.R, cp.S), (cp.sh, cp.sw), (cp.ph, cp.pw), dx))
+            elif need_dx:
                 add_expected(n.x, dx)
             if dres is not None:
                 add_expected(n.residual, dres)
         elif n.kind in ('max', 'avg'):
+            if n in absorbed:
+                continue                          # checked together with its conv above
             x = fused_y[n] if n in fused_y else act(n.x)
             upd('pool', rel(act(n.y), O.pool_fwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw))), n.name)
             if n not in fused_y:

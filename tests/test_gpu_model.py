@@ -49,6 +49,8 @@ def test_train_step_local_parity(name, nc, B, S):
     worst = check_plan(hip, B, mask)
     print(name, 'node-local worst rel errors:', {k: '%.2e' % v for k, v in worst.items()})
     assert worst['raw'] < 3e-3 and worst['y'] < 3e-3 and worst['pool'] < 3e-3
+    # pool branch run as avgpool(conv1x1(x)): the two bf16 roundings sit at other places than in the oracle's reference order
+    assert worst['raw_cp'] < 6e-3 and worst['dW_cp'] < 2e-2
     assert worst['stats'] < 1e-4
     assert worst['head'] < 1e-4
     assert worst['dW'] < 1e-2 and worst['dgamma'] < 1e-2 and worst['dbeta'] < 1e-2

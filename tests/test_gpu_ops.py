@@ -361,3 +361,29 @@ def test_adam_matches_torch_adam_over_steps(ctx):
     assert (pd.cpu() - pr).abs().max().item() < 2e-6
     assert torch.allclose(m.cpu(), mr, rtol=1e-5, atol=1e-8)
     assert torch.allclose(v.cpu(), vr, rtol=2e-5, atol=1e-8)        # fma contraction vs torch's mul_/addcmul_
+
+
+@pytest.mark.parametrize('N,Cc,H,W,ld,dtype', [(3, 64, 35, 35, 288, 0), (2, 192, 17, 17, 192, 0), (5, 32, 8, 8, 96, 1), (1, 8, 3, 3, 8, 0)])
+def test_bn_stats_of_a_stored_tensor(ctx, N, Cc, H, W, ld, dtype):
+    """ifcbk_bn_stats (batch statistics of the pooled conv output of a commuted pool branch): per-1024-row partial sums of
+    the STORED values; their finalize gives the mean / biased variance torch computes on the same tensor."""
+    from ifcb_classifier_amd import _lib
+    tdt = torch.bfloat16 if dtype == 0 else torch.float32
+    g = torch.Generator().manual_seed(N + Cc)
+    buf = (torch.randn(N, H, W, ld, generator=g) * 1.5 + 0.3).to(tdt).cuda()      # the tensor is a channel slice of a wider one
+    x = buf[..., 8:8 + Cc] if ld >= Cc + 8 else buf[..., :Cc]
+    M = N * H * W
+    rows = ctx.lib.ifcbk_bn_stats_rows(M)
+    assert rows == (M + 1023) // 1024
+    part = torch.full((rows, 2, Cc), float('nan'), device='cuda')
+    d = _lib.BnDesc(M, Cc, ld, ld, 1, dtype, 1e-3, 0.1)
+    ctx.call('ifcbk_bn_stats', C.byref(d), _lib.ptr(x), _lib.ptr(part), _lib.cur_stream())
+    torch.cuda.synchronize()
+    xs = x.float().reshape(M, Cc).double().cpu()
+    s = part.double().cpu().sum(0)
+    assert torch.isfinite(part).all()
+    assert torch.allclose(s[0], xs.sum(0), rtol=2e-6, atol=1e-3)
+    assert torch.allclose(s[1], (xs * xs).sum(0), rtol=2e-6, atol=1e-3)
+    for r in range(rows):       # every partial row covers exactly its 1024 rows
+        blk = xs[r * 1024:(r + 1) * 1024]
+        assert torch.allclose(part[r, 0].double().cpu(), blk.sum(0), rtol=1e-5, atol=1e-3)
