@@ -97,6 +97,8 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                          (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], p[8], (int)o->i[2],
                                          (float*)p[9], (float*)p[10], pacc, st);
         case IFCBK_OP_BN_STATS: return ifcbk_bn_stats(c, &o->u.bn, p[0], (float*)p[1], st);
+        case IFCBK_OP_AVGPOOL_AFFINE:
+            return ifcbk_avgpool3x3_affine(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (o->flags >> 2) & 1, p[3], st);
         case IFCBK_OP_BN_APPLY_MAXPOOL:
             return ifcbk_bn_apply_maxpool(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (int)o->i[0], p[3], (uint8_t*)p[4], st);
         case IFCBK_OP_BN_BWD_MAXPOOL:
@@ -356,7 +358,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_BN_STATS: snprintf(name, cap, "bn_stats_kernel"); break;
         case IFCBK_OP_MAXPOOL_FWD: snprintf(name, cap, "maxpool_fwd_kernel"); break;
         case IFCBK_OP_MAXPOOL_BWD: snprintf(name, cap, "maxpool_bwd_kernel"); break;
-        case IFCBK_OP_AVGPOOL_FWD: snprintf(name, cap, "avgpool_fwd_kernel"); break;
+        case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_AVGPOOL_AFFINE: snprintf(name, cap, "avgpool_fwd_kernel"); break;
         case IFCBK_OP_AVGPOOL_BWD: snprintf(name, cap, "avgpool_bwd_kernel"); break;
         case IFCBK_OP_ADAM: snprintf(name, cap, "adam_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK: snprintf(name, cap, "weight_pack_kernel"); break;
@@ -393,7 +395,7 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             by = ((double)d.N * d.H * d.W * (2 * 2 + 2) + (double)d.N * d.P * d.Q * 3 * 2) * d.C;   // x twice, dx once; pooled grad + arg-max twice
             break;
         }
-        case IFCBK_OP_MAXPOOL_FWD: case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_MAXPOOL_BWD: case IFCBK_OP_AVGPOOL_BWD: {
+        case IFCBK_OP_MAXPOOL_FWD: case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_MAXPOOL_BWD: case IFCBK_OP_AVGPOOL_BWD: case IFCBK_OP_AVGPOOL_AFFINE: {
             const ifcbk_pool_desc& d = o->u.pool;
             by = ((double)d.N * d.H * d.W + (double)d.N * d.P * d.Q) * d.C * 2;
             break;

@@ -182,7 +182,8 @@ struct Pool3Args {
 // kernel) or 4.5 (first fast path); these kernels are bound by L2 requests, not HBM.
 constexpr int AVG_SEG = 8;
 template <class T>
-__global__ __launch_bounds__(256) void avgpool3x3s1_kernel(const T* in, T* out, Pool3Args a, int accumulate) {
+__global__ __launch_bounds__(256) void avgpool3x3s1_kernel(const T* in, T* out, Pool3Args a, int accumulate,
+                                                           const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0) {
     constexpr int E = Chunk<T>::N;
     constexpr int TW = 4;
     const uint32_t i = (a.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * 256u + threadIdx.x;
@@ -195,6 +196,13 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_kernel(const T* in, T* out, 
     const int hbeg = (int)(t2 - n * a.f_b.d) * AVG_SEG;
     const int hend = min(hbeg + AVG_SEG, a.H);                // output rows [hbeg, hend)
     const float inv = 1.f / 9.f;
+    // optional epilogue y = act(round(avg) * scale[c] + shift[c]): the eval-mode BatchNorm of a pool branch that runs as
+    // avgpool(conv1x1(x)); the average is rounded to the storage type first, like the pooled tensor training stores
+    float esc[E], esh[E];
+    if (ep_scale) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { esc[j] = ep_scale[c + j]; esh[j] = ep_shift[c + j]; }
+    }
     float p2[TW][E], p1[TW][E];                               // horizontal 3-sums of input rows hh-2, hh-1
 #pragma unroll
     for (int k = 0; k < TW; ++k)
@@ -239,6 +247,13 @@ __global__ __launch_bounds__(256) void avgpool3x3s1_kernel(const T* in, T* out, 
                 float o[E];
 #pragma unroll
                 for (int j = 0; j < E; ++j) o[j] = ((p2[k][j] + p1[k][j]) + cur[k][j]) * inv;
+                if (ep_scale) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        o[j] = Chunk<T>::round(o[j]) * esc[j] + esh[j];
+                        if (ep_relu) o[j] = fmaxf(o[j], 0.f);
+                    }
+                }
                 T* op = orow + (int64_t)ww * a.ldy;
                 if (accumulate) {
                     float g[E];
@@ -709,6 +724,17 @@ extern "C" int ifcbk_avgpool_fwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const
     if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const float*)x, (float*)y, a);
     else hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(cdiv(a.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, a);
     IFCBK_LAUNCH_CHECK(ctx, "avgpool_fwd");
+    return 0;
+}
+extern "C" int ifcbk_avgpool3x3_affine(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, const float* scale, const float* shift,
+                                       int relu, void* y, void* stream) {
+    if (int e = pool_check(ctx, d)) return e;
+    if (!scale || !shift) IFCBK_FAIL(ctx, IFCBK_EINVAL, "avgpool3x3_affine: scale/shift required");
+    Pool3Args f;
+    if (!make_pool3(d, 0, &f)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "avgpool3x3_affine: 3x3 / stride 1 / pad 1 pools only");
+    if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(avgpool3x3s1_kernel<float>, dim3(cdiv(f.total, 256)), dim3(256), 0, ST, (const float*)x, (float*)y, f, 0, scale, shift, relu);
+    else hipLaunchKernelGGL(avgpool3x3s1_kernel<bf16_t>, dim3(cdiv(f.total, 256)), dim3(256), 0, ST, (const bf16_t*)x, (bf16_t*)y, f, 0, scale, shift, relu);
+    IFCBK_LAUNCH_CHECK(ctx, "avgpool3x3_affine");
     return 0;
 }
 extern "C" int ifcbk_avgpool_bwd(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* dy, void* dx, int accumulate, void* stream) {

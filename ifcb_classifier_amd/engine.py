@@ -226,7 +226,8 @@ class Engine:
         # zeros, and conv1x1(0) = 0).  In TRAINING the engine runs the conv first -- as one more member of the block's
         # sibling GEMM on x -- and pools its pf = 32..192 output channels instead of the block's 192..2048 input channels:
         # the pool's traffic shrinks 4-10x in both directions and the branch needs no conv launches of its own.  BatchNorm
-        # then normalises the pooled tensor, whose batch statistics come from ifcbk_bn_stats.  Eval keeps the reference order.
+        # then normalises the pooled tensor, whose batch statistics come from ifcbk_bn_stats; in eval mode the pool applies the
+        # folded BatchNorm affine + ReLU in its epilogue (ifcbk_avgpool3x3_affine).
         self.commute_pool = os.environ.get('IFCBK_COMMUTE_POOL', '1') != '0' and self.fuse_siblings
         nread = {}
         for m in net.nodes:
@@ -574,6 +575,20 @@ class Engine:
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
                         continue
+                    if not train and n.cpool is not None:
+                        # inference twin of the commuted pool branch: plain 1x1 conv of the block input into the branch's slice of
+                        # the sibling tensor, then avgpool with the eval-BN affine + ReLU in its epilogue
+                        cp = n.cpool
+                        pre, ldpre = self._pre_ptr(n)
+                        dpre = ConvDesc(N, cp.x.H, cp.x.W, cp.x.C, cp.x.buf.C, n.K, 1, 1, 1, 1, 0, 0, n.P, n.Q, ldpre, n.Cw, self.cdtype)
+                        rpre = ('gr', id(g), n.koff, n.koff + n.K)
+                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(cp.x), wk, pre, None), conv=dpre, lane=L,
+                                reads=[ra(cp.x)], writes=[rpre])
+                        ppd = PoolDesc(N, cp.x.H, cp.x.W, n.K, ldpre, 3, 3, 1, 1, 1, 1, cp.P, cp.Q, n.y.buf.C, self.cdtype)
+                        lst.add(_lib.OP_AVGPOOL_AFFINE, cp.name + '(' + n.name + ')',
+                                p=(pre, self._stat(n, 4), self._stat(n, 5), self._aptr(n.y)), flags=4 if n.relu else 0, pool=ppd,
+                                lane=L, reads=[rpre], writes=[ra(n.y)])
+                        continue
                     if not train:
                         # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
                         lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
@@ -660,7 +675,7 @@ class Engine:
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
                         continue
-                    if train and n in absorbed:
+                    if n in absorbed:
                         continue                  # runs behind its 1x1 conv, on that conv's output (see __init__)
                     if n.kind == 'max':
                         if train and n in fused_pool_nodes:

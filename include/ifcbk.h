@@ -223,6 +223,11 @@ int ifcbk_bn_apply_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, 
  * part [ifcbk_bn_stats_rows(M)][2][C], to be reduced by ifcbk_bn_finalize like a conv epilogue's partials.
  * Replaces the statistics half of [TV] BasicConv2d's nn.BatchNorm2d in training mode (reference call site
  * neuston_models.py:66-68).                                                                                              */
+/* Eval-mode twin of the same reordering: y = act(avgpool3x3(s1,p1)(x) * scale[c] + shift[c]), the pool of a branch that runs
+ * as avgpool(conv1x1(x)) with the BatchNorm affine (+ReLU) of [TV] BasicConv2d applied to the pooled value (rounded to the
+ * storage type first, as training stores it).  3x3 / stride 1 / pad 1 only.                                             */
+int ifcbk_avgpool3x3_affine(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, const float* scale, const float* shift,
+                            int relu, void* y, void* stream);
 int ifcbk_bn_stats_rows(int64_t M);
 int ifcbk_bn_stats(ifcbk_ctx*, const ifcbk_bn_desc* d, const void* x, float* part, void* stream);
 
@@ -260,7 +265,7 @@ enum {
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
     IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
-    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS
+    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE
 };
 typedef struct {
     int32_t kind;
