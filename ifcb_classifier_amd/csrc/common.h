@@ -16,6 +16,8 @@ struct ifcbk_ctx {
     hipStream_t lane_st[IFCBK_MAX_LANES];   // lanes 1.. of ifcbk_run_program (lane 0 is the caller's stream)
     hipEvent_t xev[64];  // cross-lane ordering events, used round-robin
     int n_xev, xev_next;
+    hipEvent_t* cev;     // ordering events of stream captures: one per edge, never reused inside a capture
+    int n_cev, cev_next, capturing;
     void* zeros;         // 4 KiB of zeros: source address of padded / out-of-range LDS-DMA chunks
     hipEvent_t* ev;      // profiling events for ifcbk_run_program
     int n_ev;

@@ -29,6 +29,8 @@ extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if (c->lane_st[l]) (void)hipStreamDestroy(c->lane_st[l]);
     for (int i = 0; i < c->n_xev; ++i) (void)hipEventDestroy(c->xev[i]);
+    for (int i = 0; i < c->n_cev; ++i) (void)hipEventDestroy(c->cev[i]);
+    free(c->cev);
     for (int i = 0; i < c->n_ev; ++i) (void)hipEventDestroy(c->ev[i]);
     free(c->ev);
     for (int s = 0; s < 256; ++s) {
@@ -156,8 +158,16 @@ static int lane_resources(ifcbk_ctx* c, int used) {
 }
 
 static int lane_order(ifcbk_ctx* c, hipStream_t waiter, hipStream_t waited) {
-    hipEvent_t ev = c->xev[c->xev_next];
-    c->xev_next = (c->xev_next + 1) & 63;
+    hipEvent_t ev;
+    if (c->capturing) {
+        // a stream capture must not record an event twice (re-recording one whose earlier record a captured wait still
+        // refers to crashed the runtime with three lanes): one event per edge, pre-created by ifcbk_program_capture
+        if (c->cev_next >= c->n_cev) IFCBK_FAIL(c, IFCBK_EINVAL, "lane_order: capture event pool exhausted");
+        ev = c->cev[c->cev_next++];
+    } else {
+        ev = c->xev[c->xev_next];
+        c->xev_next = (c->xev_next + 1) & 63;
+    }
     IFCBK_HIP(c, hipEventRecord(ev, waited));
     IFCBK_HIP(c, hipStreamWaitEvent(waiter, ev, 0));
     return IFCBK_OK;
@@ -257,6 +267,18 @@ extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, i
     int used = 1;
     for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
     if (int e = lane_resources(c, used)) return e;
+    // one ordering event per fork / wait / join edge of this program (upper bound: 3 per op + 2 per lane)
+    {
+        const int need = 3 * n + 2 * IFCBK_MAX_LANES;
+        if (c->n_cev < need) {
+            hipEvent_t* ev = (hipEvent_t*)realloc(c->cev, sizeof(hipEvent_t) * need);
+            if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "program_capture: event pool");
+            c->cev = ev;
+            for (int i = c->n_cev; i < need; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->cev[i], hipEventDisableTiming));
+            c->n_cev = need;
+        }
+        c->cev_next = 0;
+    }
     // capture on a private stream: the caller's stream may be the legacy default stream, which cannot capture
     hipStream_t cs = nullptr;
     IFCBK_HIP(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -265,7 +287,9 @@ extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, i
         (void)hipStreamDestroy(cs);
         IFCBK_FAIL(c, IFCBK_EHIP, "program_capture: hipStreamBeginCapture: %s", hipGetErrorString(he));
     }
+    c->capturing = 1;
     const int rc = run_lanes(c, ops, n, cs, nullptr);            // records; the lanes fork from and join `cs`
+    c->capturing = 0;
     hipGraph_t g = nullptr;
     he = hipStreamEndCapture(cs, &g);                            // always ends the capture, also after a failed op
     (void)hipStreamDestroy(cs);

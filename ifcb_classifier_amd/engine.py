@@ -368,13 +368,16 @@ class Engine:
             if b.name.endswith(':raw'):
                 continue
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
-        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2'))))      # program lanes (branch-parallel streams)
+        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '4'))))      # program lanes (branch-parallel streams) of the training programs
+        self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (hipGraph capture: <= 2, see replay)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
         # launch list (6.73 vs 6.85 ms); the train fwd+bwd graph is 4 % SLOWER (28.7 vs 27.6 ms per step: the graph's own
         # branch scheduling loses to the lane assignment below) -- so the default is 'eval'.  IFCBK_GRAPH=0 | eval | all
         gm = os.environ.get('IFCBK_GRAPH', 'eval')
-        self.graph_eval = gm not in ('0', 'off', 'none')
-        self.graph_train = gm in ('1', 'all', 'train')
+        # (capturing a 3- or 4-lane program crashes inside the ROCm 7.0 runtime -- a segfault in stream capture, not an error
+        # code; 2-lane captures are fine and are what the eval forward uses)
+        self.graph_eval = gm not in ('0', 'off', 'none') and self.NL_eval <= 2
+        self.graph_train = gm in ('1', 'all', 'train') and self.NL <= 2
         self.wgrad_side_lane = os.environ.get('IFCBK_WGRAD_SIDE', '0') != '0' and self.NL > 1
         self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
         max_raw = max(n.P * n.Q * n.K for n in self.convs)
@@ -514,22 +517,30 @@ class Engine:
         for m in net.nodes:
             if m.kind != 'head':
                 producers.setdefault(m.y.buf.id, []).append(m)
-        lane_of, started = {}, {}
-        for m in net.nodes:
-            if m.aux:
-                lane_of[m] = 1 % NL       # the auxiliary classifier (pool, 2 convs, fc) runs beside Mixed_7a..7c
-                continue
-            if m.kind == 'head':
-                lane_of[m] = 0
-                continue
-            prods = producers.get(m.x.buf.id, [])
-            if (len(prods) == 1 and prods[0].y.is_full and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1
-                    and prods[0] in lane_of):
-                lane_of[m] = lane_of[prods[0]]
-            else:
-                kk = started.get(m.x.buf.id, 0)
-                started[m.x.buf.id] = kk + 1
-                lane_of[m] = kk % NL
+
+        def assign_lanes(nl):
+            lanes, started = {}, {}
+            for m in net.nodes:
+                if m.aux:
+                    lanes[m] = 1 % nl     # the auxiliary classifier (pool, 2 convs, fc) runs beside Mixed_7a..7c
+                    continue
+                if m.kind == 'head':
+                    lanes[m] = 0
+                    continue
+                prods = producers.get(m.x.buf.id, [])
+                if (len(prods) == 1 and prods[0].y.is_full and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1
+                        and prods[0] in lanes):
+                    lanes[m] = lanes[prods[0]]
+                else:
+                    kk = started.get(m.x.buf.id, 0)
+                    started[m.x.buf.id] = kk + 1
+                    lanes[m] = kk % nl
+            return lanes
+
+        # training and eval programs get their own lane counts: measured (B=256) 2 / 3 / 4 lanes = 25.9 / 25.5 / 25.3 ms per
+        # train step but 6.12 / 6.63 / 6.78 ms per eval forward (its kernels are few and wide: more lanes only add waits)
+        lane_of = assign_lanes(NL)
+        lane_eval = assign_lanes(self.NL_eval)
 
         # ---- resources for the lane scheduler: channel ranges of tensors
         def ra(v):
@@ -575,6 +586,7 @@ class Engine:
                 for lst, train in ((fwd_t, True), (fwd_e, False)):
                     if n.aux and not train:
                         continue
+                    Le = lane_eval[n]
                     if not train and n.cpool is not None:
                         # inference twin of the commuted pool branch: plain 1x1 conv of the block input into the branch's slice of
                         # the sibling tensor, then avgpool with the eval-BN affine + ReLU in its epilogue
@@ -582,18 +594,18 @@ class Engine:
                         pre, ldpre = self._pre_ptr(n)
                         dpre = ConvDesc(N, cp.x.H, cp.x.W, cp.x.C, cp.x.buf.C, n.K, 1, 1, 1, 1, 0, 0, n.P, n.Q, ldpre, n.Cw, self.cdtype)
                         rpre = ('gr', id(g), n.koff, n.koff + n.K)
-                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(cp.x), wk, pre, None), conv=dpre, lane=L,
+                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(cp.x), wk, pre, None), conv=dpre, lane=Le,
                                 reads=[ra(cp.x)], writes=[rpre])
                         ppd = PoolDesc(N, cp.x.H, cp.x.W, n.K, ldpre, 3, 3, 1, 1, 1, 1, cp.P, cp.Q, n.y.buf.C, self.cdtype)
                         lst.add(_lib.OP_AVGPOOL_AFFINE, cp.name + '(' + n.name + ')',
                                 p=(pre, self._stat(n, 4), self._stat(n, 5), self._aptr(n.y)), flags=4 if n.relu else 0, pool=ppd,
-                                lane=L, reads=[rpre], writes=[ra(n.y)])
+                                lane=Le, reads=[rpre], writes=[ra(n.y)])
                         continue
                     if not train:
                         # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
                         lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
                                 p=(self._aptr(n.x), wk, self._aptr(n.y), self._stat(n, 4), self._stat(n, 5), res),
-                                i=(ldr,), flags=4 if n.relu else 0, conv=d, lane=L,
+                                i=(ldr,), flags=4 if n.relu else 0, conv=d, lane=Le,
                                 reads=[ra(n.x)] + ([ra(n.residual)] if n.residual is not None else []), writes=[ra(n.y)])
                         continue
                     if g is not None:
@@ -677,14 +689,15 @@ class Engine:
                         continue
                     if n in absorbed:
                         continue                  # runs behind its 1x1 conv, on that conv's output (see __init__)
+                    Lx = L if train else lane_eval[n]
                     if n.kind == 'max':
                         if train and n in fused_pool_nodes:
                             continue              # done by the producing conv's bn_apply_maxpool
                         lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd,
-                                lane=L, reads=[ra(n.x)], writes=[ra(n.y), ram(k)])
+                                lane=Lx, reads=[ra(n.x)], writes=[ra(n.y), ram(k)])
                     else:
                         lst.add(_lib.OP_AVGPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y)), pool=pd,
-                                lane=L, reads=[ra(n.x)], writes=[ra(n.y)])
+                                lane=Lx, reads=[ra(n.x)], writes=[ra(n.y)])
                 bwd_groups.append(('pool', n, pd, k))
             elif n.kind == 'head':
                 hd = HeadDesc(N, n.HW, n.C, n.x.buf.C, n.NC, self.cdtype, 2.0)
@@ -694,7 +707,7 @@ class Engine:
                         continue
                     mask = _vp(n.mask) if (train and n.dropout) else None
                     lst.add(_lib.OP_HEAD_FWD, n.name, p=(self._aptr(n.x), mask, self._pptr(wkey), self._pptr(bkey), _vp(n.feat), _vp(n.logits)), head=hd,
-                            lane=L, reads=[ra(n.x)], writes=[('hd', id(n), 0, 1)])
+                            lane=L if train else lane_eval[n], reads=[ra(n.x)], writes=[('hd', id(n), 0, 1)])
                 bwd_groups.append(('head', n, hd))
 
         # backward in reverse node order, resolving first-writer / accumulate flags
@@ -942,6 +955,9 @@ class Engine:
         g = pl.graphs.get(name)
         if g is None:
             prog = getattr(pl, name)
+            if len(prog.lanes) > 2:
+                raise RuntimeError('hipGraph capture of a %d-lane program is not supported (the ROCm 7.0 runtime crashes in stream '
+                                   'capture with more than two forked streams): build the engine with IFCBK_LANES=2' % len(prog.lanes))
             g = pl.graphs[name] = self.ctx.capture(prog.arr, prog.n)
         self.ctx.graph_launch(g, self.stream())
 
