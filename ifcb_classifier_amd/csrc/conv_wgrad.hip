@@ -388,6 +388,164 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_cols(WgradArgs a) {
         }
 }
 
+// ---------------------------------------------------------------- row-streaming weight gradient of the 3x3 stem layers
+// Conv2d_2a / 2b (32 input channels, 149^2 / 147^2 maps): as a GEMM over (r,s,c) columns the kernels above re-read every
+// input pixel nine times (once per tap) and every dy pixel three times (once per 128-column tile) from L2 -- 3.9 GB of
+// L2->LDS traffic for 1.06 GB of tensors, which is what bounds them.  Here a block walks down output rows
+// like conv_rows3x3: every x row goes to LDS ONCE (4-slot ring, chunk-column layout, one zero pixel left of the image) and
+// serves the three output rows and nine taps that use it, every dy row once (2 slots).  The taps are the same transposing
+// fragment reads at shifted pixel addresses (a pixel shift is a uniform 16-byte address shift in the chunk-column layout, so
+// the bank pattern of conv_wgrad_cols carries over).  A block owns 32 output channels (blockIdx selects the K half) and all
+// 288 columns: 18 (tap, 16-channel) units x 2 k-tiles of accumulators spread over the four waves; it loops over
+// (image, 16-row strip) units and writes ONE fp32 slab at the end (512 blocks -> the usual fixed-order wgrad_reduce).
+constexpr int ST_RSEG = 16;            // output rows per work unit
+constexpr int ST_CS = 2688;            // chunk-column stride in bytes: 168 pixels x 16 B (= 128 mod 256: conflict-free tr reads)
+constexpr int ST_XROW = 4 * ST_CS;     // one x row: 4 chunk columns (32 channels)
+constexpr int ST_DROW = 4 * ST_CS;     // one dy row of the block's 32 output channels
+struct StemArgs {
+    const void* x;
+    const void* dy;
+    float* slab;
+    unsigned xbytes, dybytes;
+    int N, H, W, ldx, P, Q, ldy, K, pad, nstrip, units, nb, kh;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[4 * ST_XROW];
+    __shared__ __attribute__((aligned(16))) unsigned char sD[2 * ST_DROW];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int kh = lin % a.kh, b = lin / a.kh;           // K half (32 output channels) and slab split of this block
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // LDS-DMA roles: 12 wave-instructions fill a row image (4 columns x 3 pixel groups; lane = pixel); wave w issues
+    // instructions w, w+4, w+8 of the x row and of the dy row.  Pixel groups start at 0, 64 and 104 (x: 168 pixels) or 96
+    // (dy: 160 pixels): the last group overlaps the second instead of spilling into the next column.
+    int xoff[3], doff[3];          // byte offset inside an image row (x) / output row (dy), or -1
+    unsigned xdst[3], ddst[3];     // LDS byte offset inside the row image
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int inst = wave + 4 * j;
+        const int col = inst / 3, grp = inst - col * 3;
+        const int xi = (grp == 0 ? 0 : grp == 1 ? 64 : 104) + lane;         // LDS pixel of the x image: image column xi - 1
+        const int wcol = xi - 1;
+        xoff[j] = (wcol >= 0 && wcol < a.W) ? (wcol * a.ldx + col * 8) * 2 : -1;
+        xdst[j] = (unsigned)(col * ST_CS + (xi - lane) * 16);
+        const int qi = (grp == 0 ? 0 : grp == 1 ? 64 : 96) + lane;
+        doff[j] = qi < a.Q ? (qi * a.ldy + kh * 32 + col * 8) * 2 : -1;
+        ddst[j] = (unsigned)(col * ST_CS + (qi - lane) * 16);
+    }
+#define ST_ISSUE_X(n_, h_)                                                                                     \
+    {                                                                                                           \
+        const int hh_ = (h_);                                                                                   \
+        const bool ok_ = hh_ >= 0 && hh_ < a.H;                                                                 \
+        const unsigned rb_ = (unsigned)(((n_) * a.H + hh_) * a.W * a.ldx) * 2u;                                 \
+        unsigned char* dst_ = sX + ((hh_ + 8) & 3) * ST_XROW;                                                   \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                         \
+            const unsigned vo = (ok_ && xoff[j] >= 0) ? rb_ + (unsigned)xoff[j] : OOB;                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(dst_ + xdst[j]), 16, vo, 0, 0, 0);           \
+        }                                                                                                       \
+    }
+#define ST_ISSUE_D(n_, p_, pend_)                                                                              \
+    {                                                                                                           \
+        const int pp_ = (p_);                                                                                   \
+        const bool ok_ = pp_ < (pend_);                                                                         \
+        const unsigned rb_ = (unsigned)(((n_) * a.P + pp_) * a.Q * a.ldy) * 2u;                                 \
+        unsigned char* dst_ = sD + (pp_ & 1) * ST_DROW;                                                         \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                         \
+            const unsigned vo = (ok_ && doff[j] >= 0) ? rb_ + (unsigned)doff[j] : OOB;                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lptr_t)(dst_ + ddst[j]), 16, vo, 0, 0, 0);           \
+        }                                                                                                       \
+    }
+
+    // transposing fragment reads (as conv_wgrad_cols): lane (g, lq, lp) addresses pixel 4g+lq (then +16), channels 4lp..+3 of
+    // a 16-channel tile = chunk column lp>>1, 8-byte half lp&1
+    const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+    const unsigned lane_off = (unsigned)((lp >> 1) * ST_CS + (4 * g + lq) * 16 + (lp & 1) * 8);
+    const unsigned dbase = (unsigned)(size_t)(lptr_t)sD + lane_off;
+    const unsigned xbase = (unsigned)(size_t)(lptr_t)sX + lane_off;
+    // this wave's units: u = wave + 4i (i < 5), u < 18: tap = u >> 1 (r = tap / 3, s = tap % 3), channel tile = u & 1
+    int ur[5], uoff[5];
+    bool ulive[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int u = wave + 4 * i;
+        ulive[i] = u < 18;
+        const int tap = ulive[i] ? (u >> 1) : 0;
+        ur[i] = tap / 3;
+        uoff[i] = (u & 1) * 2 * ST_CS + (tap - ur[i] * 3 + 1 - a.pad) * 16;      // channel tile + column shift s + 1 - pad
+    }
+    f32x4_t acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i][0] = acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define ST_TR(lo, hi, addr, OFF)                                                                                \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
+                 : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF), "n"((OFF) + 256));
+
+    for (int unit = b; unit < a.units; unit += a.nb) {
+        const int n = unit / a.nstrip;
+        const int p0 = (unit - n * a.nstrip) * ST_RSEG;
+        const int p1 = min(p0 + ST_RSEG, a.P);
+        __syncthreads();                                 // the previous unit's last row is consumed
+        ST_ISSUE_X(n, p0 - a.pad)
+        ST_ISSUE_X(n, p0 - a.pad + 1)
+        ST_ISSUE_X(n, p0 - a.pad + 2)
+        ST_ISSUE_D(n, p0, p1)
+        for (int p = p0; p < p1; ++p) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                             // x rows p-pad .. p-pad+2 and dy row p are in LDS; row p-1 is consumed
+            if (p + 1 < p1) {
+                ST_ISSUE_X(n, p - a.pad + 3)             // its slot held row p-pad-1
+                ST_ISSUE_D(n, p + 1, p1)                 // its slot held dy row p-1
+            }
+            const unsigned da = dbase + (unsigned)((p & 1) * ST_DROW);
+            unsigned xa[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) xa[i] = xbase + (unsigned)(((p - a.pad + ur[i] + 8) & 3) * ST_XROW + uoff[i]);
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                s16x4_t alo[2], ahi[2], blo[5], bhi[5];
+                ST_TR(alo[0], ahi[0], da, ks * 512)
+                ST_TR(alo[1], ahi[1], da, ks * 512 + 2 * ST_CS)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) ST_TR(blo[i], bhi[i], xa[i], ks * 512)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]));
+#pragma unroll
+                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(blo[i]), "+v"(bhi[i]));
+                const bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[0], ahi[0], 0, 1, 2, 3, 4, 5, 6, 7));
+                const bf16x8_t fa1 = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[1], ahi[1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (!ulive[i]) continue;             // wave-uniform
+                    const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[i], bhi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb, acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+#undef ST_TR
+#undef ST_ISSUE_X
+#undef ST_ISSUE_D
+    // slab [nb][K][288]: lane holds rows k = 4g+j of a 16 x 16 tile, column lane & 15
+    float* out = a.slab + (size_t)b * a.K * 288;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (!ulive[i]) continue;
+        const int u = wave + 4 * i;
+        const int col = (u >> 1) * 32 + (u & 1) * 16 + (lane & 15);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(size_t)(kh * 32 + kt * 16 + 4 * g + j) * 288 + col] = acc[i][kt][j];
+    }
+}
+
 // ---------------------------------------------------------------- fp32 parity-mode wgrad
 // Same decomposition on v_mfma_f32_16x16x4_f32.  Tiles are [32 pixels][128 fp32 columns] (512-byte rows, one wave
 // LDS-DMA instruction fills two rows); a lane's MFMA operand is ONE float -- A[k = lane>>4][m = lane&15] -- so the
@@ -537,7 +695,7 @@ int pick_mt(int K, int maxmt) {
     return best;
 }
 
-struct Plan { int mt, cols, tilesM, tilesN, nsplit, split_len; size_t ws; };
+struct Plan { int mt, cols, stem, tilesM, tilesN, nsplit, split_len; size_t ws; };
 
 Plan make_plan(const ifcbk_conv_desc* d) {
     Plan p;
@@ -549,6 +707,22 @@ Plan make_plan(const ifcbk_conv_desc* d) {
     static int force = -2;
     if (force == -2) { const char* e = getenv("IFCBK_WGRAD_COLS"); force = e ? atoi(e) : -1; }
     p.cols = d->dtype == IFCBK_F32 ? 0 : (force >= 0 ? force : (p.mt <= 2));
+    // row-streaming kernel for the 3x3 / stride-1 / 32-input-channel stem layers (IFCBK_WGRAD_STEM=0 disables)
+    static int stem = -1;
+    if (stem < 0) { const char* e = getenv("IFCBK_WGRAD_STEM"); stem = e ? atoi(e) : 1; }
+    p.stem = stem && d->dtype == IFCBK_BF16 && d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->C == 32 &&
+             d->Cw == 32 && d->pad_h == d->pad_w && d->pad_h <= 1 && d->Q <= 160 && d->W <= 166 && (d->K == 32 || d->K == 64);
+    if (p.stem) {
+        const int kh = d->K / 32;
+        p.mt = 0;
+        p.nsplit = 512 / kh;
+        const int units = d->N * cdiv(d->P, ST_RSEG);
+        if (p.nsplit > units) p.nsplit = units;
+        p.tilesM = p.tilesN = 1;
+        p.split_len = 0;
+        p.ws = (size_t)p.nsplit * d->K * RSC * sizeof(float);
+        return p;
+    }
     p.tilesM = cdiv(d->K, 32 * p.mt);
     p.tilesN = cdiv(RSC, BNW);
     int tiles = p.tilesM * p.tilesN;
@@ -635,6 +809,12 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
             case 3: hipLaunchKernelGGL(conv_wgrad_f32<3>, grid, block, 0, st, a); break;
             default: hipLaunchKernelGGL(conv_wgrad_f32<4>, grid, block, 0, st, a); break;
         }
+    } else if (p.stem) {
+        StemArgs sa;
+        sa.x = x; sa.dy = dy; sa.slab = (float*)ctx->ws; sa.xbytes = a.xbytes; sa.dybytes = a.dybytes;
+        sa.N = d->N; sa.H = d->H; sa.W = d->W; sa.ldx = d->ldx; sa.P = d->P; sa.Q = d->Q; sa.ldy = d->ldy; sa.K = d->K;
+        sa.pad = d->pad_h; sa.nstrip = cdiv(d->P, ST_RSEG); sa.units = d->N * sa.nstrip; sa.kh = d->K / 32; sa.nb = p.nsplit;
+        hipLaunchKernelGGL(conv_wgrad_stem, dim3(sa.nb * sa.kh), dim3(256), 0, st, sa);
     } else {
         switch (p.mt) {
             case 1: launch<1>(a, p, st); break;

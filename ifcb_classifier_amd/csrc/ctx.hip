@@ -369,6 +369,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int mt = 0, cols = 0;
             ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
             if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
+            else if (mt == 0) snprintf(name, cap, "conv_wgrad_stem");
             else if (cols) snprintf(name, cap, "conv_wgrad_cols<%d, 4>", mt);
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
             break;

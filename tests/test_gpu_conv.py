@@ -54,6 +54,7 @@ CASES = [
     (2, 32, 21, 19, 64, 3, 3, 1, 1, 1, 1),         # row-streaming stem kernel: 32 -> 64, pad 1 (dgrad 64 -> 32)
     (1, 32, 20, 149, 32, 3, 3, 1, 1, 0, 0),        # ... full 149-wide rows (10 pixel tiles), two row segments
     (3, 32, 35, 18, 32, 3, 3, 1, 1, 0, 0),         # ... three row segments per image
+    (2, 32, 37, 147, 64, 3, 3, 1, 1, 1, 1),        # row-streaming stem weight gradient: full-width rows, pad 1, two K halves, 3 strips
 ]
 
 
