@@ -399,9 +399,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_cols(WgradArgs a) {
 // 288 columns: 18 (tap, 16-channel) units x 2 k-tiles of accumulators spread over the four waves; it loops over
 // (image, 16-row strip) units and writes ONE fp32 slab at the end (512 blocks -> the usual fixed-order wgrad_reduce).
 constexpr int ST_RSEG = 16;            // output rows per work unit
-constexpr int ST_CS = 2688;            // chunk-column stride in bytes: 168 pixels x 16 B (= 128 mod 256: conflict-free tr reads)
-constexpr int ST_XROW = 4 * ST_CS;     // one x row: 4 chunk columns (32 channels)
-constexpr int ST_DROW = 4 * ST_CS;     // one dy row of the block's 32 output channels
+// template <CT, NG>: CT = input channels / 16; NG = 64-pixel DMA groups per row image: 3 -> rows of up to 160 output pixels
+// (168-pixel x image, 5 k-steps of 32 pixels: Conv2d_2a / 2b), 2 -> up to 96 output pixels (104-pixel x image, 3 k-steps:
+// Conv2d_4a with CT = 5, the 56x56 resnet layers with CT = 4).  Chunk-column stride = image pixels x 16 B, = 128 mod 256
+// (conflict-free transposing reads).
 struct StemArgs {
     const void* x;
     const void* dy;
@@ -410,7 +411,19 @@ struct StemArgs {
     int N, H, W, ldx, P, Q, ldy, K, pad, nstrip, units, nb, kh;
 };
 
+template <int CT, int NG>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
+    constexpr int ST_CS = NG == 3 ? 2688 : 1664;         // 168 / 104 pixels x 16 B
+    constexpr int KS = NG == 3 ? 5 : 3;                  // k-steps of 32 pixels per output row
+    constexpr int XG1 = NG == 3 ? 104 : 40;              // first pixel of the LAST DMA group of an x row image (it overlaps the
+    constexpr int DG1 = NG == 3 ? 96 : 32;               // previous group instead of spilling into the next column); dy likewise
+    constexpr int XC = 2 * CT;                           // chunk columns of an x row
+    constexpr int ST_XROW = XC * ST_CS;
+    constexpr int ST_DROW = 4 * ST_CS;                   // one dy row of the block's 32 output channels
+    constexpr int NXI = (XC * NG + 3) / 4;               // x-row DMA instructions per wave
+    constexpr int NDI = (4 * NG + 3) / 4;                // dy-row DMA instructions per wave
+    constexpr int NU = 9 * CT;                           // (tap, 16-channel tile) units
+    constexpr int UPW = (NU + 3) / 4;                    // units per wave
     __shared__ __attribute__((aligned(16))) unsigned char sX[4 * ST_XROW];
     __shared__ __attribute__((aligned(16))) unsigned char sD[2 * ST_DROW];
     const int t = threadIdx.x, lane = t & 63;
@@ -424,17 +437,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
     // LDS-DMA roles: 12 wave-instructions fill a row image (4 columns x 3 pixel groups; lane = pixel); wave w issues
     // instructions w, w+4, w+8 of the x row and of the dy row.  Pixel groups start at 0, 64 and 104 (x: 168 pixels) or 96
     // (dy: 160 pixels): the last group overlaps the second instead of spilling into the next column.
-    int xoff[3], doff[3];          // byte offset inside an image row (x) / output row (dy), or -1
-    unsigned xdst[3], ddst[3];     // LDS byte offset inside the row image
+    int xoff[NXI], doff[NDI];      // byte offset inside an image row (x) / output row (dy), or -1
+    unsigned xdst[NXI], ddst[NDI]; // LDS byte offset inside the row image
+    bool xlive[NXI], dlive[NDI];   // this wave issues instruction j (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NXI; ++j) {
         const int inst = wave + 4 * j;
-        const int col = inst / 3, grp = inst - col * 3;
-        const int xi = (grp == 0 ? 0 : grp == 1 ? 64 : 104) + lane;         // LDS pixel of the x image: image column xi - 1
+        xlive[j] = inst < XC * NG;
+        const int col = inst / NG, grp = inst - col * NG;
+        const int xi = (grp == NG - 1 ? XG1 : grp * 64) + lane;             // LDS pixel of the x image: image column xi - 1
         const int wcol = xi - 1;
         xoff[j] = (wcol >= 0 && wcol < a.W) ? (wcol * a.ldx + col * 8) * 2 : -1;
         xdst[j] = (unsigned)(col * ST_CS + (xi - lane) * 16);
-        const int qi = (grp == 0 ? 0 : grp == 1 ? 64 : 96) + lane;
+    }
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) {
+        const int inst = wave + 4 * j;
+        dlive[j] = inst < 4 * NG;
+        const int col = inst / NG, grp = inst - col * NG;
+        const int qi = (grp == NG - 1 ? DG1 : grp * 64) + lane;
         doff[j] = qi < a.Q ? (qi * a.ldy + kh * 32 + col * 8) * 2 : -1;
         ddst[j] = (unsigned)(col * ST_CS + (qi - lane) * 16);
     }
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
         const bool ok_ = hh_ >= 0 && hh_ < a.H;                                                                 \
         const unsigned rb_ = (unsigned)(((n_) * a.H + hh_) * a.W * a.ldx) * 2u;                                 \
         unsigned char* dst_ = sX + ((hh_ + 8) & 3) * ST_XROW;                                                   \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                         \
+        _Pragma("unroll") for (int j = 0; j < NXI; ++j) if (xlive[j]) {                                         \
             const unsigned vo = (ok_ && xoff[j] >= 0) ? rb_ + (unsigned)xoff[j] : OOB;                          \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(dst_ + xdst[j]), 16, vo, 0, 0, 0);           \
         }                                                                                                       \
@@ -455,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
         const bool ok_ = pp_ < (pend_);                                                                         \
         const unsigned rb_ = (unsigned)(((n_) * a.P + pp_) * a.Q * a.ldy) * 2u;                                 \
         unsigned char* dst_ = sD + (pp_ & 1) * ST_DROW;                                                         \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                         \
+        _Pragma("unroll") for (int j = 0; j < NDI; ++j) if (dlive[j]) {                                         \
             const unsigned vo = (ok_ && doff[j] >= 0) ? rb_ + (unsigned)doff[j] : OOB;                          \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lptr_t)(dst_ + ddst[j]), 16, vo, 0, 0, 0);           \
         }                                                                                                       \
@@ -467,20 +488,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
     const unsigned lane_off = (unsigned)((lp >> 1) * ST_CS + (4 * g + lq) * 16 + (lp & 1) * 8);
     const unsigned dbase = (unsigned)(size_t)(lptr_t)sD + lane_off;
     const unsigned xbase = (unsigned)(size_t)(lptr_t)sX + lane_off;
-    // this wave's units: u = wave + 4i (i < 5), u < 18: tap = u >> 1 (r = tap / 3, s = tap % 3), channel tile = u & 1
-    int ur[5], uoff[5];
-    bool ulive[5];
+    // this wave's units: u = wave + 4i (i < UPW), u < NU: tap = u / CT (r = tap / 3, s = tap % 3), channel tile = u % CT
+    int ur[UPW], uoff[UPW];
+    bool ulive[UPW];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < UPW; ++i) {
         const int u = wave + 4 * i;
-        ulive[i] = u < 18;
-        const int tap = ulive[i] ? (u >> 1) : 0;
+        ulive[i] = u < NU;
+        const int tap = ulive[i] ? u / CT : 0;
+        const int ct = ulive[i] ? u - tap * CT : 0;
         ur[i] = tap / 3;
-        uoff[i] = (u & 1) * 2 * ST_CS + (tap - ur[i] * 3 + 1 - a.pad) * 16;      // channel tile + column shift s + 1 - pad
+        uoff[i] = ct * 2 * ST_CS + (tap - ur[i] * 3 + 1 - a.pad) * 16;            // channel tile + column shift s + 1 - pad
     }
-    f32x4_t acc[5][2];
+    f32x4_t acc[UPW][2];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) acc[i][0] = acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < UPW; ++i) acc[i][0] = acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #define ST_TR(lo, hi, addr, OFF)                                                                                \
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                   \
@@ -503,24 +525,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
                 ST_ISSUE_D(n, p + 1, p1)                 // its slot held dy row p-1
             }
             const unsigned da = dbase + (unsigned)((p & 1) * ST_DROW);
-            unsigned xa[5];
+            unsigned xa[UPW];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) xa[i] = xbase + (unsigned)(((p - a.pad + ur[i] + 8) & 3) * ST_XROW + uoff[i]);
+            for (int i = 0; i < UPW; ++i) xa[i] = xbase + (unsigned)(((p - a.pad + ur[i] + 8) & 3) * ST_XROW + uoff[i]);
 #pragma unroll
-            for (int ks = 0; ks < 5; ++ks) {
-                s16x4_t alo[2], ahi[2], blo[5], bhi[5];
+            for (int ks = 0; ks < KS; ++ks) {
+                s16x4_t alo[2], ahi[2], blo[UPW], bhi[UPW];
                 ST_TR(alo[0], ahi[0], da, ks * 512)
                 ST_TR(alo[1], ahi[1], da, ks * 512 + 2 * ST_CS)
 #pragma unroll
-                for (int i = 0; i < 5; ++i) ST_TR(blo[i], bhi[i], xa[i], ks * 512)
+                for (int i = 0; i < UPW; ++i) ST_TR(blo[i], bhi[i], xa[i], ks * 512)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]));
 #pragma unroll
-                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(blo[i]), "+v"(bhi[i]));
+                for (int i = 0; i < UPW; ++i) asm volatile("" : "+v"(blo[i]), "+v"(bhi[i]));
                 const bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[0], ahi[0], 0, 1, 2, 3, 4, 5, 6, 7));
                 const bf16x8_t fa1 = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(alo[1], ahi[1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < UPW; ++i) {
                     if (!ulive[i]) continue;             // wave-uniform
                     const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[i], bhi[i], 0, 1, 2, 3, 4, 5, 6, 7));
                     acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb, acc[i][0], 0, 0, 0);
@@ -532,17 +554,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem(StemArgs a) {
 #undef ST_TR
 #undef ST_ISSUE_X
 #undef ST_ISSUE_D
-    // slab [nb][K][288]: lane holds rows k = 4g+j of a 16 x 16 tile, column lane & 15
-    float* out = a.slab + (size_t)b * a.K * 288;
+    // slab [nb][K][9 * C]: lane holds rows k = 4g+j of a 16 x 16 tile, column lane & 15
+    constexpr int RSCW = 9 * 16 * CT;
+    float* out = a.slab + (size_t)b * a.K * RSCW;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < UPW; ++i) {
         if (!ulive[i]) continue;
         const int u = wave + 4 * i;
-        const int col = (u >> 1) * 32 + (u & 1) * 16 + (lane & 15);
+        const int col = u * 16 + (lane & 15);                  // (tap * CT + ct) * 16: the (r, s, c) column
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[(size_t)(kh * 32 + kt * 16 + 4 * g + j) * 288 + col] = acc[i][kt][j];
+            for (int j = 0; j < 4; ++j) out[(size_t)(kh * 32 + kt * 16 + 4 * g + j) * RSCW + col] = acc[i][kt][j];
     }
 }
 
@@ -707,11 +730,18 @@ Plan make_plan(const ifcbk_conv_desc* d) {
     static int force = -2;
     if (force == -2) { const char* e = getenv("IFCBK_WGRAD_COLS"); force = e ? atoi(e) : -1; }
     p.cols = d->dtype == IFCBK_F32 ? 0 : (force >= 0 ? force : (p.mt <= 2));
-    // row-streaming kernel for the 3x3 / stride-1 / 32-input-channel stem layers (IFCBK_WGRAD_STEM=0 disables)
+    // row-streaming kernel for the 3x3 / stride-1 stem layers (IFCBK_WGRAD_STEM: 0 off, 1 the 32-channel layers only, 2 also
+    // Conv2d_4a's 80 channels: 0.687 -> 0.616 ms, less than the 32-channel layers gain because 71-pixel rows fill only 74 % of
+    // their three 32-pixel k-steps and the layer is MFMA- rather than load-bound)
     static int stem = -1;
-    if (stem < 0) { const char* e = getenv("IFCBK_WGRAD_STEM"); stem = e ? atoi(e) : 1; }
-    p.stem = stem && d->dtype == IFCBK_BF16 && d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->C == 32 &&
-             d->Cw == 32 && d->pad_h == d->pad_w && d->pad_h <= 1 && d->Q <= 160 && d->W <= 166 && (d->K == 32 || d->K == 64);
+    if (stem < 0) { const char* e = getenv("IFCBK_WGRAD_STEM"); stem = e ? atoi(e) : 2; }
+    // stem: 1 = <2,3> (32 channels, rows up to 160 pixels), 2 = <5,2> (80 channels, rows up to 96 pixels: Conv2d_4a)
+    p.stem = 0;
+    if (stem && d->dtype == IFCBK_BF16 && d->R == 3 && d->S == 3 && d->stride_h == 1 && d->stride_w == 1 && d->Cw == d->C &&
+        d->pad_h == d->pad_w && d->pad_h <= 1 && d->K % 32 == 0 && d->K <= 512) {
+        if (d->C == 32 && d->Q <= 160 && d->W <= 166 && d->K <= 64) p.stem = 1;
+        else if (d->C == 80 && d->Q <= 96 && d->W <= 102 && stem >= 2) p.stem = 2;
+    }
     if (p.stem) {
         const int kh = d->K / 32;
         p.mt = 0;
@@ -814,7 +844,8 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
         sa.x = x; sa.dy = dy; sa.slab = (float*)ctx->ws; sa.xbytes = a.xbytes; sa.dybytes = a.dybytes;
         sa.N = d->N; sa.H = d->H; sa.W = d->W; sa.ldx = d->ldx; sa.P = d->P; sa.Q = d->Q; sa.ldy = d->ldy; sa.K = d->K;
         sa.pad = d->pad_h; sa.nstrip = cdiv(d->P, ST_RSEG); sa.units = d->N * sa.nstrip; sa.kh = d->K / 32; sa.nb = p.nsplit;
-        hipLaunchKernelGGL(conv_wgrad_stem, dim3(sa.nb * sa.kh), dim3(256), 0, st, sa);
+        if (p.stem == 2) hipLaunchKernelGGL((conv_wgrad_stem<5, 2>), dim3(sa.nb * sa.kh), dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL((conv_wgrad_stem<2, 3>), dim3(sa.nb * sa.kh), dim3(256), 0, st, sa);
     } else {
         switch (p.mt) {
             case 1: launch<1>(a, p, st); break;

@@ -55,6 +55,7 @@ CASES = [
     (1, 32, 20, 149, 32, 3, 3, 1, 1, 0, 0),        # ... full 149-wide rows (10 pixel tiles), two row segments
     (3, 32, 35, 18, 32, 3, 3, 1, 1, 0, 0),         # ... three row segments per image
     (2, 32, 37, 147, 64, 3, 3, 1, 1, 1, 1),        # row-streaming stem weight gradient: full-width rows, pad 1, two K halves, 3 strips
+    (2, 80, 21, 73, 192, 3, 3, 1, 1, 0, 0),        # ... its 80-channel form (Conv2d_4a): six K blocks, 104-pixel row images
 ]
 
 
