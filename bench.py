@@ -289,7 +289,7 @@ def main():
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None
             try:        # HBM bytes per launch of the same kernel from the committed PMC passes (scripts/collect_traffic.py)
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1j_traffic.json')))['kernels']
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1k_traffic.json')))['kernels']
                 traffic = round(tj[dom]['hbm_bytes_per_launch'])
             except Exception:
                 pass
