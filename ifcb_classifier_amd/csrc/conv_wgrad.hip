@@ -678,12 +678,25 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_f32(WgradArgs a) {
 // dw[k][rs][cw] (+)= sum_split slab[split][k][rs*C + cw]; 64 outputs x 4 split lanes per block, the 4 lane sums are
 // combined in a fixed order (bitwise reproducible)
 // (k_off, Kseg): the rows [k_off, k_off+Kseg) of a horizontally fused conv go to their own destination tensor
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, float* dw, int nsplit, int K, int RS, int C, int Cw,
-                                                    int accumulate, int k_off, int Kseg) {
+// up to 8 destination tensors (the members of a sibling GEMM own consecutive ranges of output channels): ONE launch reduces
+// the slabs into all of them -- the blocks of segment s start at blk0[s]
+struct ReduceSegs {
+    float* dw[8];
+    int k_off[8], kseg[8], blk0[9];
+    int nseg;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, ReduceSegs sg_, int nsplit, int K, int RS, int C, int Cw,
+                                                    int accumulate) {
     __shared__ float part[4][64];
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+        if (q < sg_.nseg && (int)blockIdx.x >= sg_.blk0[q]) si = q;
+    float* dw = sg_.dw[si];
+    const int k_off = sg_.k_off[si], Kseg = sg_.kseg[si];
     const int64_t total = (int64_t)Kseg * RS * Cw;
     const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    const int64_t i = (int64_t)((int)blockIdx.x - sg_.blk0[si]) * 64 + o;
     float s = 0.f;
     if (i < total) {
         int cw = (int)(i % Cw);
@@ -855,14 +868,24 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
         }
     }
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
-    int k_off = 0;
-    for (int sgi = 0; sgi < nseg; ++sgi) {
-        int64_t total = (int64_t)kseg[sgi] * d->R * d->S * d->Cw;
-        hipLaunchKernelGGL(wgrad_reduce, dim3(cdiv(total, 64)), dim3(256), 0, st, (const float*)ctx->ws, dws[sgi], p.nsplit,
-                           d->K, d->R * d->S, d->C, d->Cw, accumulate, k_off, kseg[sgi]);
-        IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
-        k_off += kseg[sgi];
+    ReduceSegs rs;
+    rs.nseg = nseg;
+    int k_off = 0, blk = 0;
+    for (int sgi = 0; sgi < 8; ++sgi) {
+        const bool live = sgi < nseg;
+        rs.dw[sgi] = live ? dws[sgi] : nullptr;
+        rs.k_off[sgi] = k_off;
+        rs.kseg[sgi] = live ? kseg[sgi] : 0;
+        rs.blk0[sgi] = blk;
+        if (live) {
+            blk += cdiv((int64_t)kseg[sgi] * d->R * d->S * d->Cw, 64);
+            k_off += kseg[sgi];
+        }
     }
+    rs.blk0[8] = blk;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(blk), dim3(256), 0, st, (const float*)ctx->ws, rs, p.nsplit, d->K, d->R * d->S, d->C,
+                       d->Cw, accumulate);
+    IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return 0;
 }
 
