@@ -324,3 +324,32 @@ def test_batch_beyond_the_descriptor_window_is_chunked_in_eval_and_refused_in_tr
     with pytest.raises(RuntimeError, match='larger max_batch'):
         m.eval()
         m(torch.rand(13, 3, 224, 224).cuda())
+
+
+@pytest.mark.gpu
+def test_lane_count_does_not_change_the_result(monkeypatch):
+    """The lane count only decides which stream a kernel is launched on (data-parallel jobs use 2 lanes, a single GPU 4, one
+    lane is plain stream order): every reduction has a fixed order and the per-lane scratch buffers carry no state, so
+    1, 2 and 4 lanes must produce the same bits -- a dependency the 2- or 4-lane schedule misses would show up here."""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    B, S = 6, 299
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.rand(B, 3, S, S, generator=g) for _ in range(2)]
+    ys = [torch.randint(0, 7, (B,), generator=g) for _ in range(2)]
+    results = []
+    for lanes in ('1', '2', '4'):
+        monkeypatch.setenv('IFCBK_LANES', lanes)
+        eng = Engine(graph.build('inception_v3', 7, pretrained=False), device=0, max_batch=B)
+        assert eng.NL == int(lanes)
+        eng.init_weights(seed=4321)
+        eng.dropout_seed = 5
+        for x, y in zip(xs, ys):
+            eng.load_input_nchw(x.cuda())
+            eng.target[:B].copy_(y)
+            eng.train_step(B)
+        torch.cuda.synchronize()
+        results.append((eng.loss.clone(), eng.P.clone(), eng.RB.clone()))
+        del eng
+    for r in results[1:]:
+        assert torch.equal(results[0][0], r[0]) and torch.equal(results[0][1], r[1]) and torch.equal(results[0][2], r[2])
