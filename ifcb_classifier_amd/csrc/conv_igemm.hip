@@ -40,6 +40,9 @@ struct ConvArgs {
     int ostr_h, ostr_w, base_h, base_w, ish, isw;
     int M, Kg;
     int accumulate;
+    // MODE 4 (eval-mode sibling GEMM): the output channels are cut into up to 4 segments with their own destination tensors
+    int seg_n, seg_end[4], seg_ld[4], seg_aff[4];     // channel end (exclusive), pixel stride, 1 = affine + ReLU / 0 = raw
+    void* seg_y[4];
     int PQ;
     int tilesN;
     // MODE 2 (one parity class of a stride-2 dgrad): sub-filter taps inside the full flipped filter, scattered output
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
 
     // 1x1 filter without padding (most layers of the inception / resnet graphs): the gather is a plain row read --
     // per-lane offsets are constants and the k advance is a scalar (soffset): no per-step VALU address work at all
-    const bool plain = (MODE == 0 || MODE == 3) && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    const bool plain = (MODE == 0 || MODE == 3 || MODE == 4) && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
     unsigned va[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) va[j] = bh[j] >= 0 ? (unsigned)(off0[j] + csrc * CE) * (unsigned)ES : OOB;
@@ -337,6 +340,19 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                     sh[j] = a.ep_shift[nn + j];
                 }
             }
+            // MODE 4: this thread's chunk column belongs to one output segment (its own tensor, stride, affine or raw)
+            T* segbase = (T*)a.y + nn;
+            int segld = a.ldy;
+            bool seg_aff = true;
+            if (MODE == 4) {
+                int si = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q + 1 < a.seg_n && nn >= a.seg_end[q]) si = q + 1;
+                segbase = (T*)a.seg_y[si] + (nn - (si ? a.seg_end[si - 1] : 0));
+                segld = a.seg_ld[si];
+                seg_aff = a.seg_aff[si] != 0;
+            }
             // rows of this thread in batches of UB: the read-modify-write operands (accumulating dgrad, residual) of a
             // whole batch are requested before the first is used -- one exposed memory latency per batch instead of per row
             // (an accumulating 1x1 dgrad into a 288-channel block input ran at 1.5 TB/s with a load -> wait -> store loop)
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                     // the chunk as it is stored (rounded for bf16): when nothing modifies it (training forward, first-writer
                     // dgrad) the raw bits go straight to memory; the statistics use packed fp32 math (v_pk_add / v_pk_fma)
                     const typename Chunk<T>::raw_t rawc = Chunk<T>::load_raw(sC + r * LDC + cc * CE);
-                    T* dst = (T*)a.y + opx[u] * a.ldy + nn;
+                    T* dst = MODE == 4 ? segbase + opx[u] * segld : (T*)a.y + opx[u] * a.ldy + nn;
                     float fv[CE];
                     if (a.part || a.accumulate || a.ep_scale) Chunk<T>::widen(rawc, fv);
                     if (BSTAT) {
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
                             s2p[j / 2] += v * v;
                         }
                     }
-                    if (!(a.accumulate || a.ep_scale)) {
+                    if (!(a.accumulate || a.ep_scale) || (MODE == 4 && !seg_aff)) {
                         *reinterpret_cast<typename Chunk<T>::raw_t*>(dst) = rawc;
                         continue;
                     }
@@ -730,7 +746,8 @@ template <class T, int NT, int WM, int NSTAGE>
 void launch(const ConvArgs& a, hipStream_t st) {
     int tilesM = cdiv(a.M, 64 * WM);
     dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
-    if (a.bs_raw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 3>), grid, block, 0, st, a);
+    if (a.seg_n) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 4>), grid, block, 0, st, a);
+    else if (a.bs_raw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 3>), grid, block, 0, st, a);
     else if (a.wKg) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 2>), grid, block, 0, st, a);
     else if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 0>), grid, block, 0, st, a);
@@ -783,7 +800,7 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6), a.M, 64 * wm);
     a.tilesN = cdiv(a.K, 32 * nt);
     if ((int64_t)cdiv(a.M, 64 * wm) * a.tilesN >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: grid too large");
-    if (ws_shape_ok(dtype, a.M, a.K, a.Kg) && !a.bs_raw && !a.wKg && !(a.ish | a.isw) && !a.accumulate && !a.ep_res) {
+    if (ws_shape_ok(dtype, a.M, a.K, a.Kg) && !a.seg_n && !a.bs_raw && !a.wKg && !(a.ish | a.isw) && !a.accumulate && !a.ep_res) {
         switch (nt) {
             case 1: launch_ws<1>(a, st); break;
             case 2: launch_ws<2>(a, st); break;
@@ -843,8 +860,32 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     return cdiv(M, 64 * pick_wm(M, d->K));
 }
 
+struct FwdSegs { int n, end[4], ld[4], aff[4]; void* y[4]; };
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
-                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream);
+                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
+                         const FwdSegs* seg = nullptr);
+
+extern "C" int ifcbk_conv2d_fwd_affine_segments(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, int nseg,
+                                                void* const* ys, const int32_t* ldys, const int32_t* ksegs, const int32_t* affine,
+                                                const float* scale, const float* shift, void* stream) {
+    if (!d || nseg < 1 || nseg > 4 || !ys || !ldys || !ksegs || !affine || !scale || !shift)
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine_segments: bad args");
+    FwdSegs sg;
+    sg.n = nseg;
+    int end = 0;
+    const int ce = dtype_chunk(d->dtype);
+    for (int q = 0; q < 4; ++q) {
+        const bool live = q < nseg;
+        if (live) {
+            if (!ys[q] || ksegs[q] <= 0 || ksegs[q] % ce || ldys[q] % ce)
+                IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine_segments: segment %d: null / size not a multiple of %d", q, ce);
+            end += ksegs[q];
+        }
+        sg.end[q] = end; sg.ld[q] = live ? ldys[q] : 0; sg.aff[q] = live ? affine[q] : 0; sg.y[q] = live ? ys[q] : nullptr;
+    }
+    if (end != d->K) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine_segments: segment sizes sum to %d, K=%d", end, d->K);
+    return conv_fwd_impl(ctx, d, x, w, ys[0], nullptr, scale, shift, nullptr, 0, 1, stream, &sg);
+}
 
 extern "C" int ifcbk_conv2d_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y,
                                 float* bn_part, void* stream) {
@@ -859,15 +900,21 @@ extern "C" int ifcbk_conv2d_fwd_affine(ifcbk_ctx* ctx, const ifcbk_conv_desc* d,
 }
 
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
-                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream) {
+                         const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
+                         const FwdSegs* seg) {
     if (int e = check_desc(ctx, d)) return e;
-    if (fwd_rows(d) && !residual)
+    if (fwd_rows(d) && !residual && !seg)
         return ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,
                                       bn_part, scale, shift, relu, (hipStream_t)stream);
     ConvArgs a;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
     a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0;
+    a.seg_n = seg ? seg->n : 0;
+    for (int q = 0; q < 4; ++q) {
+        a.seg_end[q] = seg ? seg->end[q] : 0; a.seg_ld[q] = seg ? seg->ld[q] : 0; a.seg_aff[q] = seg ? seg->aff[q] : 0;
+        a.seg_y[q] = seg ? seg->y[q] : nullptr;
+    }
     const int es = dtype_esize(d->dtype);
     a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es); a.wbytes = (unsigned)((int64_t)d->K * d->R * d->S * d->C * es);
     a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
@@ -929,6 +976,7 @@ static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, 
     ConvArgs a;
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
     a.x = dy; a.w = wT; a.y = dx; a.part = bs ? bs->part : nullptr;
+    a.seg_n = 0;
     a.bs_raw = bs ? bs->raw : nullptr; a.bs_ld = bs ? bs->ld : 0;
     a.bs_mean = bs ? bs->mean : nullptr; a.bs_invstd = bs ? bs->invstd : nullptr;
     a.bs_scale = bs ? bs->scale : nullptr; a.bs_shift = bs ? bs->shift : nullptr;

@@ -98,6 +98,17 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_bn_bwd_partials(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
                                          (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], p[8], (int)o->i[2],
                                          (float*)p[9], (float*)p[10], pacc, st);
+        case IFCBK_OP_CONV_FWD_AFFINE_SEG: {
+            // i[s] = channels | pixel stride << 20 | affine << 40 of segment s (0 = unused); p[2..5] = destinations
+            void* ys[4];
+            int32_t ld[4], ks[4], af[4];
+            int ns = 0;
+            for (int k = 0; k < 4 && (o->i[k] & 0xfffff) > 0; ++k) {
+                ys[ns] = p[2 + k]; ks[ns] = (int32_t)(o->i[k] & 0xfffff); ld[ns] = (int32_t)((o->i[k] >> 20) & 0xfffff);
+                af[ns] = (int32_t)((o->i[k] >> 40) & 1); ++ns;
+            }
+            return ifcbk_conv2d_fwd_affine_segments(c, &o->u.conv, p[0], p[1], ns, ys, ld, ks, af, (const float*)p[6], (const float*)p[7], st);
+        }
         case IFCBK_OP_BN_STATS: return ifcbk_bn_stats(c, &o->u.bn, p[0], (float*)p[1], st);
         case IFCBK_OP_AVGPOOL_AFFINE:
             return ifcbk_avgpool3x3_affine(c, &o->u.pool, p[0], (const float*)p[1], (const float*)p[2], (o->flags >> 2) & 1, p[3], st);
@@ -335,6 +346,11 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
     if (!o || !name || cap < 1) return IFCBK_EINVAL;
     name[0] = 0;
     switch (o->kind) {
+        case IFCBK_OP_CONV_FWD_AFFINE_SEG: {
+            const ifcbk_conv_desc& d = o->u.conv;
+            snprintf(name, cap, "conv_igemm<unsigned short, %d, 2, 2, 4>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q));
+            break;
+        }
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
@@ -396,7 +412,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
 extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
     double fl = 0, by = 0;
     switch (o->kind) {
-        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD:
+        case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_FWD_AFFINE_SEG: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD:
         case IFCBK_OP_CONV_WGRAD_SEG: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
             const ifcbk_conv_desc& d = o->u.conv;
             double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;

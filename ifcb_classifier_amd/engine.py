@@ -229,6 +229,7 @@ class Engine:
         # then normalises the pooled tensor, whose batch statistics come from ifcbk_bn_stats; in eval mode the pool applies the
         # folded BatchNorm affine + ReLU in its epilogue (ifcbk_avgpool3x3_affine).
         self.commute_pool = os.environ.get('IFCBK_COMMUTE_POOL', '1') != '0' and self.fuse_siblings
+        self.eval_groups = os.environ.get('IFCBK_EVAL_GROUPS', '1') != '0'      # eval forward: sibling 1x1 convs as one GEMM
         nread = {}
         for m in net.nodes:
             for v in ((m.x, getattr(m, 'residual', None)) if m.kind == 'conv' else (m.x,)):
@@ -596,6 +597,33 @@ class Engine:
                     if n.aux and not train:
                         continue
                     Le = lane_eval[n]
+                    if not train and g is not None and self.eval_groups:
+                        # inference: the sibling 1x1 convs of a block as ONE GEMM with per-segment destinations
+                        # (ifcbk_conv2d_fwd_affine_segments): members with their folded BatchNorm + ReLU straight into their output
+                        # tensors, a commuted pool branch raw into its slice of the sibling tensor (its pool applies the affine)
+                        if first_of_group:
+                            gd = self._group_desc(g, N)
+                            ys, iv, wr = [], [], []
+                            for m in g.members:
+                                if m.cpool is not None:
+                                    pre, ldpre = self._pre_ptr(m)
+                                    ys.append(pre); iv.append(m.K | (ldpre << 20)); wr.append(('gr', id(g), m.koff, m.koff + m.K))
+                                else:
+                                    ys.append(self._aptr(m.y)); iv.append(m.K | (m.y.buf.C << 20) | (1 << 40)); wr.append(ra(m.y))
+                            ys += [None] * (4 - len(ys))
+                            iv += [0] * (4 - len(iv))
+                            lst.add(_lib.OP_CONV_FWD_AFFINE_SEG, '+'.join(m.name for m in g.members),
+                                    p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), ys[0], ys[1], ys[2], ys[3],
+                                       self._stat(g.members[0], 4), self._stat(g.members[0], 5)),
+                                    i=iv, conv=gd, lane=Le, reads=[ra(g.x)], writes=wr)
+                        if n.cpool is not None:
+                            cp = n.cpool
+                            pre, ldpre = self._pre_ptr(n)
+                            ppd = PoolDesc(N, cp.x.H, cp.x.W, n.K, ldpre, 3, 3, 1, 1, 1, 1, cp.P, cp.Q, n.y.buf.C, self.cdtype)
+                            lst.add(_lib.OP_AVGPOOL_AFFINE, cp.name + '(' + n.name + ')',
+                                    p=(pre, self._stat(n, 4), self._stat(n, 5), self._aptr(n.y)), flags=4 if n.relu else 0, pool=ppd,
+                                    lane=Le, reads=[('gr', id(g), n.koff, n.koff + n.K)], writes=[ra(n.y)])
+                        continue
                     if not train and n.cpool is not None:
                         # inference twin of the commuted pool branch: plain 1x1 conv of the block input into the branch's slice of
                         # the sibling tensor, then avgpool with the eval-BN affine + ReLU in its epilogue

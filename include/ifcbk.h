@@ -72,6 +72,15 @@ int ifcbk_conv2d_fwd(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const vo
 int ifcbk_conv2d_fwd_affine(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y,
                             const float* scale, const float* shift, const void* residual, int ldr, int relu,
                             void* stream);
+/* Eval-mode sibling GEMM: ONE convolution whose d->K output channels belong to nseg (<= 4) consecutive segments with their own
+ * destination tensors ys[s] (pixel stride ldys[s], ksegs[s] channels; sizes sum to d->K; d->ldy is ignored).  affine[s] = 1:
+ * y = relu(conv * scale[k] + shift[k]) with the per-channel arrays indexed by the merged channel k (the folded BatchNorm of
+ * [TV] BasicConv2d); affine[s] = 0: the raw convolution (a pool branch whose average pool applies the affine afterwards).
+ * Replaces the 3-4 1x1 convolutions that read one Inception block input (inception.py InceptionA/C/E.forward), reference
+ * call site neuston_models.py:94-103,152-157 (eval forward).                                                             */
+int ifcbk_conv2d_fwd_affine_segments(ifcbk_ctx*, const ifcbk_conv_desc* d, const void* x, const void* w, int nseg,
+                                     void* const* ys, const int32_t* ldys, const int32_t* ksegs, const int32_t* affine,
+                                     const float* scale, const float* shift, void* stream);
 /* dx[n,h,w,c] (+)= sum_{k,r,s} dy[n,p,q,k] * w[k,r,s,c];  wT = bf16 [C][R][S][K] with r,s FLIPPED
  * (made by ifcbk_weight_pack).  accumulate!=0 adds into dx.                                          */
 int ifcbk_conv2d_dgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
@@ -265,7 +274,8 @@ enum {
     IFCBK_OP_HEAD_FWD, IFCBK_OP_HEAD_BWD, IFCBK_OP_SOFTMAX_XENT, IFCBK_OP_SOFTMAX,
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
     IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
-    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE
+    IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE,
+    IFCBK_OP_CONV_FWD_AFFINE_SEG
 };
 typedef struct {
     int32_t kind;
