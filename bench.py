@@ -293,6 +293,12 @@ def main():
                 traffic = round(tj[dom]['hbm_bytes_per_launch'])
             except Exception:
                 pass
+            mfma_util = None
+            try:        # MFMA-pipe busy fraction of the same kernel from the committed PMC pass (scripts/collect_mfma.py)
+                mj = json.load(open(os.path.join(ROOT, 'profiles', 'r1k_mfma.json')))['kernels']
+                mfma_util = round(mj[dom]['mfma_pipe_utilisation'], 4)
+            except Exception:
+                pass
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                                'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']),
@@ -303,7 +309,8 @@ def main():
                                         'launch; isolated_* = the same launches back to back on one lane (survey pass)' % eng.NL)
                                if use_ev else 'N > 1: rank 0, untimed survey pass (3 local steps, every op bracketed, one lane)',
                                'isolated_tflops': round(survey[dom]['flops'] / (survey[dom]['ms'] * 1e-3) / 1e12, 2),
-                               'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5)}
+                               'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5),
+                               'pmc_mfma_pipe_utilisation': mfma_util}
             if dom.startswith('conv_wgrad'):
                 # one weight-gradient op = the split-K MFMA kernel + its fixed-order fp32 reduction (wgrad_reduce): the event
                 # bracket, avg_launch_ms and achieved cover BOTH; rocprofv3 lists them as two kernels (their averages add up)
