@@ -15,13 +15,13 @@ BF16, F32 = 0, 1
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
- OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG) = range(1, 30)
+ OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD) = range(1, 31)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
-            24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine'}
+            24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd'}
 
 
 class ConvDesc(C.Structure):
@@ -183,6 +183,24 @@ class Context:
                 self.h = None
         except Exception:
             pass
+
+
+class PlanOnlyContext:
+    """``Engine(plan_only=True)``: the library's pure host-side planning helpers (tile counts, workspace sizes, kernel names)
+    without a device context; anything that would launch raises."""
+
+    def __init__(self):
+        self.lib = load()
+        self.h = None
+        self.device = None
+
+    def reserve(self, nbytes):
+        pass
+
+    def call(self, name, *args):
+        raise RuntimeError('%s: this engine was built with plan_only=True (no HIP context)' % name)
+
+    run_program = capture = graph_launch = call
 
 
 def ptr(t):

@@ -1,13 +1,42 @@
 // ctx lifetime, workspace, error text and the program runner of libifcbk.
 #include "common.h"
+#include <execinfo.h>
+#include <signal.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+
+// IFCBK_SEGV_BACKTRACE=1: print the host call stack (frames of this library and of the HIP runtime) when the process takes a
+// SIGSEGV / SIGABRT, then die with the default action.  Diagnostic only (used to locate the runtime call that faults in a
+// multi-stream hipGraph capture); async-signal-safe calls only: backtrace_symbols_fd writes straight to stderr.
+static void segv_backtrace(int sig) {
+    static const char head[] = "\n[ifcbk] fatal signal -- host backtrace:\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void maybe_install_backtrace() {
+    static int done = 0;
+    if (done) return;
+    done = 1;
+    const char* e = getenv("IFCBK_SEGV_BACKTRACE");
+    if (!e || !atoi(e)) return;
+    void* warm[4];
+    (void)backtrace(warm, 4);          // loads libgcc now, not inside the handler
+    signal(SIGSEGV, segv_backtrace);
+    signal(SIGABRT, segv_backtrace);
+    signal(SIGBUS, segv_backtrace);
+}
 
 extern "C" const char* ifcbk_version(void) { return "ifcbk 0.1 (gfx950, bf16 MFMA)"; }
 
 extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     if (!out) return IFCBK_EINVAL;
     *out = nullptr;
+    maybe_install_backtrace();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return IFCBK_EHIP;
     ifcbk_ctx* c = (ifcbk_ctx*)calloc(1, sizeof(ifcbk_ctx));
@@ -135,6 +164,8 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
         case IFCBK_OP_ADAM:
             return ifcbk_adam_flat(c, (float*)p[0], (const float*)p[1], (float*)p[2], (float*)p[3], o->i[0], o->f[0], o->f[1],
                                    o->f[2], o->f[3], o->f[4], (int)o->i[1], o->f[5], st);
+        case IFCBK_OP_SGD:
+            return ifcbk_sgd_flat(c, (float*)p[0], (const float*)p[1], (float*)p[2], o->i[0], o->f[0], o->f[1], o->f[2], o->f[3], st);
         case IFCBK_OP_MEMSET:
             IFCBK_HIP(c, hipMemsetAsync(p[0], (int)o->i[1], (size_t)o->i[0], (hipStream_t)st));
             return 0;
@@ -402,6 +433,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_AVGPOOL_FWD: case IFCBK_OP_AVGPOOL_AFFINE: snprintf(name, cap, "avgpool_fwd_kernel"); break;
         case IFCBK_OP_AVGPOOL_BWD: snprintf(name, cap, "avgpool_bwd_kernel"); break;
         case IFCBK_OP_ADAM: snprintf(name, cap, "adam_kernel"); break;
+        case IFCBK_OP_SGD: snprintf(name, cap, "sgd_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK: snprintf(name, cap, "weight_pack_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK_MULTI: snprintf(name, cap, "weight_pack_multi_kernel"); break;
         default: break;
@@ -448,6 +480,7 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             break;
         }
         case IFCBK_OP_ADAM: by = (double)o->i[0] * 28; break;
+        case IFCBK_OP_SGD: by = (double)o->i[0] * (o->p[2] ? 20 : 12); break;
         default: break;
     }
     if (flops) *flops = fl;

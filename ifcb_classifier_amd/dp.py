@@ -9,25 +9,35 @@ the remaining segments still compute.
 """
 
 
-def segment_plan(op_offsets, padded_size, total, nseg=8):
+def segment_plan(op_offsets, padded_size, total, nseg=8, last_frac=1.0 / 24):
     """op_offsets[k]: flat-buffer element offsets of the parameter tensors finished by backward op k;
     padded_size[offset]: padded element count of that tensor; total: flat buffer length.
-    Returns [(op_begin, op_end, lo, hi)] -- ops [op_begin, op_end) finish exactly the elements [lo, hi)."""
-    target = total / float(max(1, nseg))
-    segs, start, prev_lo, lo_min, produced = [], 0, total, total, 0
+    Returns [(op_begin, op_end, lo, hi)] -- ops [op_begin, op_end) finish exactly the elements [lo, hi).
+    Buckets are about total/nseg elements, except the LAST one: its all-reduce (and the optimizer behind it) cannot
+    overlap any backward work, so the final cut is placed where at most ``last_frac`` of the buffer is left (the network's
+    first layers: the stem and first blocks hold few parameters) whenever the backward order offers a cut there."""
     n = len(op_offsets)
+    cuts, lo_min, produced = [], total, 0           # (ops consumed, lo) wherever the finished set is a contiguous tail
     for k, offs in enumerate(op_offsets):
         for off in offs:
             lo_min = min(lo_min, off)
             produced += padded_size[off]
-        last = k == n - 1
-        closed = produced == total - lo_min           # every tensor at or above lo_min is finished
-        if last and not (closed and lo_min == 0):
-            raise RuntimeError('backward op list does not cover the flat gradient buffer (covered %d of %d from %d)'
-                               % (produced, total, lo_min))
-        if (closed and prev_lo - lo_min >= target) or last:
-            segs.append((start, k + 1, lo_min, prev_lo))
-            start, prev_lo = k + 1, lo_min
+        if produced == total - lo_min and (not cuts or cuts[-1][1] != lo_min):
+            cuts.append((k + 1, lo_min))
+    if not cuts or cuts[-1][1] != 0 or produced != total:
+        raise RuntimeError('backward op list does not cover the flat gradient buffer (covered %d of %d from %d)'
+                           % (produced, total, lo_min))
+    cuts[-1] = (n, 0)
+    target = total / float(max(1, nseg))
+    small = [c for c in cuts[:-1] if 0 < c[1] <= last_frac * total]
+    final_cut = max(small, key=lambda c: c[1]) if small else None
+    segs, start, prev_lo = [], 0, total
+    for c in cuts:
+        k1, lo = c
+        last = c is cuts[-1]
+        if last or c is final_cut or (prev_lo - lo >= target and (final_cut is None or lo > final_cut[1])):
+            segs.append((start, k1, lo, prev_lo))
+            start, prev_lo = k1, lo
     return segs
 
 

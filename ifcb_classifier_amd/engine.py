@@ -146,9 +146,16 @@ class Program:
 class Engine:
     """Device state of one model replica."""
 
-    def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16'):
-        if not torch.cuda.is_available():
+    def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16', optimizer='adam',
+                 momentum=0.0, plan_only=False):
+        # plan_only: build buffers on the host and the op tables only (no HIP context, nothing can run) -- the CPU tests
+        # of the data-parallel bucket plan read the REAL backward list of a network this way
+        self.plan_only = bool(plan_only)
+        if not self.plan_only and not torch.cuda.is_available():
             raise RuntimeError('ifcb_classifier_amd needs a HIP device (MI355X); none is visible and there is no CPU path')
+        if str(optimizer).lower() not in ('adam', 'sgd'):
+            raise ValueError("optimizer must be 'adam' (the reference's only behaviour, neuston_models.py:63-64) or 'sgd'")
+        self.optimizer, self.momentum = str(optimizer).lower(), float(momentum)
         self.net = net
         if dtype not in ('bf16', 'fp32'):
             raise ValueError("dtype must be 'bf16' (performance) or 'fp32' (parity mode)")
@@ -156,9 +163,13 @@ class Engine:
         self.tdtype = torch.bfloat16 if dtype == 'bf16' else torch.float32
         self.esize = 2 if dtype == 'bf16' else 4
         self.cdtype = _lib.BF16 if dtype == 'bf16' else _lib.F32
-        self.dev = torch.device('cuda', device)
-        torch.cuda.set_device(self.dev)
-        self.ctx = _lib.Context(device)
+        if self.plan_only:
+            self.dev = torch.device('cpu')
+            self.ctx = _lib.PlanOnlyContext()
+        else:
+            self.dev = torch.device('cuda', device)
+            torch.cuda.set_device(self.dev)
+            self.ctx = _lib.Context(device)
         # the kernels address every tensor through a 32-bit buffer descriptor (2 GiB window): the largest per-image tensor
         # (inception_v3: 147x147x64 bf16 = 2.77 MB) bounds the images one launch can take (776 in bf16, 388 in fp32)
         self.requested_batch = int(max_batch)
@@ -880,15 +891,20 @@ class Engine:
         sm.add(_lib.OP_SOFTMAX, 'softmax', p=(_vp(main.logits), _vp(self.probs)), i=(N, net.NC))
         pl.softmax = Program(sm)
         opt = OpList()
-        opt.add(_lib.OP_ADAM, 'adam', p=(_vp(self.P), _vp(self.G), _vp(self.M), _vp(self.V)),
-                i=(self.nparam_padded, 1), f=(self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0))
+        if self.optimizer == 'sgd':
+            # additive option (north_star "SGD/Adam step"; upstream only has Adam): torch.optim.SGD's update, momentum buffer = M
+            opt.add(_lib.OP_SGD, 'sgd', p=(_vp(self.P), _vp(self.G), _vp(self.M) if self.momentum else None),
+                    i=(self.nparam_padded, 1), f=(self.lr, self.momentum, 0.0, 1.0))
+        else:
+            opt.add(_lib.OP_ADAM, 'adam', p=(_vp(self.P), _vp(self.G), _vp(self.M), _vp(self.V)),
+                    i=(self.nparam_padded, 1), f=(self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0))
         pl.adam = Program(opt)
         # fused train step = fwd + loss + bwd + adam + pack
         allops = OpList()
         for prog_ops in (fwd_t, lossl, bwd, opt, pack):
             allops.extend(prog_ops)
         pl.step = Program(allops)
-        pl.step_adam_idx = pl.step.find(_lib.OP_ADAM)[0]
+        pl.step_adam_idx = pl.step.find(_lib.OP_SGD if self.optimizer == 'sgd' else _lib.OP_ADAM)[0]
         # data-parallel variant: fwd+loss | backward segments (all-reduce launched after each) | adam+pack
         fl = OpList()
         fl.extend(fwd_t)
@@ -970,9 +986,7 @@ class Engine:
         from .dp import run_overlapped
         run_overlapped(self.ddp_segments(pl), lambda seg: self.run(seg[0]), self.G, all_reduce)
         self.step_count += 1
-        a = pl.adam_pack.arr[0]
-        a.i[1] = self.step_count
-        a.f[5] = 1.0 / world
+        self._set_update(pl.adam_pack.arr[0], 1.0 / world)
         self.run(pl.adam_pack)
         self.nbt += 1
         self.loss_sum += self.loss
@@ -1077,10 +1091,15 @@ class Engine:
     def backward(self, N):
         self.run(self.plan(N).bwd)
 
+    def _set_update(self, op, grad_scale=1.0):
+        """per-step scalars of the optimizer op: the step count (Adam's bias correction) and the gradient scale (1/world)"""
+        op.i[1] = self.step_count
+        op.f[3 if self.optimizer == 'sgd' else 5] = grad_scale
+
     def adam_step(self, N):
         pl = self.plan(N)
         self.step_count += 1
-        pl.adam.arr[0].i[1] = self.step_count
+        self._set_update(pl.adam.arr[0])
         self.run(pl.adam)
         self.packed = False
         self.eval_stats_ready = False
@@ -1091,21 +1110,19 @@ class Engine:
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
         self.step_count += 1
-        pl.step.arr[pl.step_adam_idx].i[1] = self.step_count
+        self._set_update(pl.step.arr[pl.step_adam_idx])
         if ev_slot is not None:
             # ev_arr: pl.step.timed(...) -- which ops to bracket with HIP events (default: all)
             if ev_arr is None:
                 if getattr(pl, 'step_timed_all', None) is None:
                     pl.step_timed_all = pl.step.timed()
                 ev_arr = pl.step_timed_all
-            ev_arr[pl.step_adam_idx].i[1] = self.step_count
+            self._set_update(ev_arr[pl.step_adam_idx])
             self.ctx.call('ifcbk_run_program_ev', ev_arr, pl.step.n, self.stream(), int(ev_slot))
         elif self.graph_train and op_ms is None:
             # fwd + loss + bwd replayed as one hipGraph; Adam (its step count is a launch argument) + repack stay plain launches
             self.replay(pl, 'fwd_bwd')
-            a = pl.adam_pack.arr[0]
-            a.i[1] = self.step_count
-            a.f[5] = 1.0
+            self._set_update(pl.adam_pack.arr[0])
             self.run(pl.adam_pack)
         else:
             self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)

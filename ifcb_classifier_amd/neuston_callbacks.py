@@ -85,12 +85,16 @@ class SaveValidationResults:
                     'training_image_basenames']
             out = {}
             for k, v in results.items():
-                if k in strs:
+                # upstream's order of tests (:128-134): ndarrays go to float32 FIRST, so input_classes / output_classes (numpy
+                # arrays) are stored as zero-based float32 and only the list-valued index series get the 1-based uint32 form
+                if isinstance(v, np.ndarray):
+                    out[k] = v.astype('f4')
+                elif isinstance(v, (np.floating, float)):       # (sklearn >= 1.x returns python floats where 0.24 gave np.float64)
+                    out[k] = np.asarray(v).astype('f4')
+                elif k in strs:
                     out[k] = np.asarray(v, dtype='object')
                 elif k in idx:
                     out[k] = np.asarray(v).astype('u4') + 1            # matlab indices are 1-based
-                elif isinstance(v, (np.ndarray, np.floating)):
-                    out[k] = np.asarray(v).astype('f4')
                 else:
                     out[k] = v
             savemat(outfile, out, do_compression=True)

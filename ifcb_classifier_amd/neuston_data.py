@@ -307,6 +307,12 @@ class IfcbBinDataset(Dataset):
         self.img_norm = parse_imgnorm(img_norm) if img_norm else None
         self.resize = resize[0] if isinstance(resize, (tuple, list)) else resize
         self.transform = RoiTransform(self.resize, self.img_norm)
+        if getattr(bin, 'schema', None) == 'v1' and not getattr(bin, 'stitched', False) \
+                and os.environ.get('IFCBK_ALLOW_UNSTITCHED_V1', '0') == '0':
+            # upstream reads old-style bins through pyifcb's InfilledImages (stitched ROI pairs, :446-449); that algorithm is
+            # not available here, and classifying the raw halves would silently change the ROI set of the bin
+            raise NotImplementedError('{}: schema-v1 (old-style) bin -- ROI stitching / infilling is not implemented on this path; '
+                                      'set IFCBK_ALLOW_UNSTITCHED_V1=1 to classify its raw ROIs knowingly'.format(bin.pid))
         for target_number, img in bin.images.items():
             self.images.append(np.ascontiguousarray(img, dtype=np.uint8))
             self.pids.append(bin.pid.with_target(target_number))

@@ -17,6 +17,9 @@ import torch.nn as nn
 from . import graph
 from .engine import Engine
 
+import pickle
+import types
+
 InceptionOutputs = namedtuple('InceptionOutputs', ['logits', 'aux_logits'])
 InceptionOutputs.__annotations__ = {'logits': torch.Tensor, 'aux_logits': torch.Tensor}
 
@@ -49,10 +52,10 @@ class _NetFn(torch.autograd.Function):
 
 
 class HipBackbone(nn.Module):
-    def __init__(self, net, device=0, max_batch=None, dtype='bf16'):
+    def __init__(self, net, device=0, max_batch=None, dtype='bf16', **engine_kw):
         super().__init__()
         max_batch = max_batch or 32
-        object.__setattr__(self, 'engine', Engine(net, device, max_batch, dtype=dtype))
+        object.__setattr__(self, 'engine', Engine(net, device, max_batch, dtype=dtype, **engine_kw))
         object.__setattr__(self, 'net', net)
         eng = self.engine
         pmap = {}
@@ -123,7 +126,79 @@ class HipBackbone(nn.Module):
         return self._train_heads[0].logits[:N].clone()
 
 
-def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None, dtype='bf16'):
+class _MissingClass(dict):
+    """stand-in for a class whose module is not installed here (pytorch_lightning's AttributeDict, callback classes ...):
+    keeps dict items, attribute state and constructor arguments so that the rest of the checkpoint can be read"""
+
+    def __init__(self, *a, **k):
+        dict.__init__(self)
+        self._args, self._kwargs = a, k
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['_state'] = state
+
+    def __reduce__(self):
+        return (dict, (dict(self),))
+
+
+def _tolerant_pickle():
+    """``pickle_module`` for torch.load: a [PL] 1.3.x checkpoint keys ``checkpoint['callbacks']`` by callback CLASS objects and
+    stores ``hyper_parameters`` as ``pytorch_lightning.utilities.parsing.AttributeDict`` -- unpickling a reference-trained
+    ``.ptl`` therefore imports pytorch_lightning (absent here).  Unknown classes resolve to dict-like stand-ins."""
+    made = {}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                key = module + '.' + name
+                if key not in made:
+                    made[key] = type(name, (_MissingClass,), {'__module__': module})
+                return made[key]
+
+    mod = types.ModuleType('ifcbk_tolerant_pickle')
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.loads = pickle.loads
+    mod.__name__ = 'pickle'
+    return mod
+
+
+def load_checkpoint_file(path):
+    """read a ``.ptl`` / ``.ckpt`` written by this package OR by the reference under Lightning 1.3.8 (f-2)"""
+    try:
+        return torch.load(path, map_location='cpu', weights_only=False)
+    except (ImportError, AttributeError, ModuleNotFoundError):
+        return torch.load(path, map_location='cpu', weights_only=False, pickle_module=_tolerant_pickle())
+
+
+def load_pretrained_weights(backbone, path):
+    """``--weights PATH``: a torchvision ``state_dict`` (e.g. inception_v3_google-1a9a5a14.pth) or a checkpoint holding one,
+    standing in for the download ``pretrained=True`` triggers upstream (neuston_models.py:23-42).  As upstream, the
+    classifier heads were replaced for ``num_o_classes`` AFTER the ImageNet weights were loaded: tensors whose shape differs
+    (fc, AuxLogits.fc) keep their fresh initialisation.  Returns (loaded, skipped) key lists."""
+    sd = load_checkpoint_file(path)
+    if isinstance(sd, dict) and 'state_dict' in sd:
+        sd = sd['state_dict']
+    sd = {(k[len('model.'):] if k.startswith('model.') else k): v for k, v in sd.items()}
+    own = backbone.state_dict()
+    take = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+    skipped = [k for k in own if k not in take]
+    heads = ('fc.', 'AuxLogits.fc.')
+    bad = [k for k in skipped if not k.startswith(heads) and not k.endswith('num_batches_tracked')]
+    if bad:
+        raise RuntimeError('--weights %s does not fit this backbone: missing or mis-shaped tensors %s%s'
+                           % (path, bad[:5], ' ...' if len(bad) > 5 else ''))
+    own.update(take)
+    backbone.load_state_dict(own)
+    return sorted(take), skipped
+
+
+def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None, dtype='bf16', **engine_kw):
     """``neuston_models.py:22-45``.  Backbones on the HIP path: inception_v3, resnet18/34/50/101/152.
     ``pretrained=True`` cannot download ImageNet weights here (no torchvision / network): it switches on
     inception's ``transform_input`` exactly as torchvision does and expects a ``load_state_dict`` to follow.
@@ -132,7 +207,7 @@ def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, m
     if model_name in ('alexnet', 'squeezenet') or model_name.startswith(('vgg', 'densenet')):
         raise NotImplementedError('%s is accepted by the reference but not built on the MI355X path yet' % model_name)
     net = graph.build(model_name, num_o_classes, pretrained)
-    return HipBackbone(net, device, max_batch, dtype)
+    return HipBackbone(net, device, max_batch, dtype, **engine_kw)
 
 
 class NeustonModel(nn.Module):
@@ -147,8 +222,11 @@ class NeustonModel(nn.Module):
         self.hparams = hparams
         self.criterion = nn.CrossEntropyLoss()
         mb = max_batch or getattr(hparams, 'batch_size', None) or 32
+        opt = str(getattr(hparams, 'optimizer', None) or 'Adam').lower()
         self.model = get_namebrand_model(hparams.MODEL, len(hparams.classes), hparams.pretrained, device, mb,
-                                         getattr(hparams, 'precision', 'bf16') or 'bf16')
+                                         getattr(hparams, 'precision', 'bf16') or 'bf16', optimizer=opt,
+                                         lr=float(getattr(hparams, 'learning_rate', None) or 0.001),
+                                         momentum=float(getattr(hparams, 'momentum', None) or 0.0))
         self.best_val_loss = np.inf
         self.best_epoch = 0
         self.agg_train_loss = 0.0
@@ -156,8 +234,12 @@ class NeustonModel(nn.Module):
         self.logged = {}
 
     def configure_optimizers(self):
+        eng = self.model.engine
+        if eng.optimizer == 'sgd':            # additive option; the reference's only behaviour is Adam(lr=0.001) (:63-64)
+            from torch.optim import SGD
+            return SGD(self.parameters(), lr=eng.lr, momentum=eng.momentum)
         from torch.optim import Adam
-        return Adam(self.parameters(), lr=0.001)
+        return Adam(self.parameters(), lr=eng.lr)
 
     def forward(self, inputs):
         return self.model(inputs)
@@ -288,16 +370,65 @@ class NeustonModel(nn.Module):
             return repr(rep)
 
     # checkpoints: the [PL] dict layout the reference reads back (neuston_net.py:173,443)
+    def optimizer_state(self):
+        """``torch.optim`` state_dict of the engine's fused optimizer in parameters() order ([PL] ``optimizer_states[0]``)"""
+        eng = self.model.engine
+        state, ids = {}, []
+        for i, (key, (o, n, shape, kind, node)) in enumerate(eng.poff.items()):
+            ids.append(i)
+            if eng.step_count == 0:
+                continue
+
+            def view(buf):
+                t = buf[o:o + n].detach().cpu()
+                return (t.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2) if kind == 'conv' else t.view(shape)).contiguous()
+            if eng.optimizer == 'sgd':
+                if eng.momentum:
+                    state[i] = dict(momentum_buffer=view(eng.M))
+            else:
+                state[i] = dict(step=eng.step_count, exp_avg=view(eng.M), exp_avg_sq=view(eng.V))
+        if eng.optimizer == 'sgd':
+            group = dict(lr=eng.lr, momentum=eng.momentum, dampening=0, weight_decay=0, nesterov=False, params=ids)
+        else:
+            group = dict(lr=eng.lr, betas=tuple(eng.betas), eps=eng.eps, weight_decay=0, amsgrad=False, params=ids)
+        return dict(state=state, param_groups=[group])
+
     def checkpoint_dict(self, epoch=0, global_step=0):
+        """the dict [PL] 1.3.8 ``trainer.save_checkpoint`` writes and ``LightningModule.load_from_checkpoint`` reads back
+        (reference: neuston_net.py:98-100,118-120,173,443): ``hparams_name`` / ``hparams_type`` tell Lightning to rebuild the
+        module as ``NeustonModel(hparams=Namespace(**hyper_parameters))``; ``callbacks`` is empty (upstream keys it by callback
+        class objects, which would force every reader to import Lightning)."""
         hp = dict(vars(self.hparams))
-        return dict(epoch=epoch, global_step=global_step, pytorch_lightning_version='1.3.8',
-                    state_dict={k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
-                    hyper_parameters=hp)
+        out = dict(epoch=epoch, global_step=global_step, state_dict={k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                   hyper_parameters=hp, hparams_name='hparams', hparams_type='Namespace', optimizer_states=[self.optimizer_state()],
+                   lr_schedulers=[], callbacks={})
+        out['pytorch-lightning_version'] = '1.3.8'
+        return out
 
     @classmethod
     def load_from_checkpoint(cls, path, device=0, max_batch=None):
-        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        """never triggers the pretrained download/--weights requirement: the state_dict in the file is the model"""
+        ckpt = load_checkpoint_file(path)
         hp = dict(ckpt['hyper_parameters'])
         obj = cls(hp, device=device, max_batch=max_batch)
         obj.load_state_dict(ckpt['state_dict'])
+        st = (ckpt.get('optimizer_states') or [None])[0]
+        if st and st.get('state'):
+            obj.load_optimizer_state(st)
         return obj
+
+    def load_optimizer_state(self, st):
+        eng = self.model.engine
+        for i, (key, (o, n, shape, kind, node)) in enumerate(eng.poff.items()):
+            ps = st['state'].get(i)
+            if not ps:
+                continue
+
+            def put(buf, t):
+                t = torch.as_tensor(t, dtype=torch.float32)
+                buf[o:o + n].copy_((t.permute(0, 2, 3, 1) if kind == 'conv' else t).reshape(-1))
+            if 'exp_avg' in ps:
+                put(eng.M, ps['exp_avg']); put(eng.V, ps['exp_avg_sq'])
+                eng.step_count = max(eng.step_count, int(ps.get('step', 0)))
+            elif 'momentum_buffer' in ps:
+                put(eng.M, ps['momentum_buffer'])

@@ -22,7 +22,7 @@ from torch.utils.data import DataLoader
 from .neuston_callbacks import SaveValidationResults, SaveTestResults
 from .neuston_data import (get_trainval_datasets, IfcbBinDataset, ImageDataset, IMG_EXTENSIONS, collate_rois,
                            rois_to_device)
-from .neuston_models import NeustonModel
+from .neuston_models import NeustonModel, load_checkpoint_file, load_pretrained_weights
 
 
 def seed_everything(seed=None):
@@ -190,6 +190,29 @@ class Trainer:
             written += cb.on_test_end(rr, model)
         return rr, written
 
+    def test_many(self, model, bins, batch_size, num_workers, callbacks):
+        """--gobig: classify the ROIs of all ``bins`` [(pid, IfcbBinDataset)] as one stream of full batches, then write one
+        result set per bin (the per-bin files are the same as without --gobig: an image's scores do not depend on its batch)."""
+        dev = model.model.engine.dev
+        cat = torch.utils.data.ConcatDataset([ds for _, ds in bins])
+        loader = DataLoader(cat, batch_size=batch_size, pin_memory=True, num_workers=num_workers, collate_fn=collate_rois)
+        probs, ids = [], []
+        for rois, pids in loader:
+            p, _ = model.eval_batch(rois_to_device(rois, dev, bins[0][1].transform))
+            probs.append(p)
+            ids.extend(pids)
+        probs = torch.cat(probs, 0).detach().cpu().numpy()
+        written, lo = [], 0
+        for bin_obj, ds in bins:
+            hi = lo + len(ds)
+            rr = model.RunResults(inputs=ids[lo:hi], outputs=probs[lo:hi], input_obj=bin_obj)
+            rr.type = 'Bin'
+            model.logged = dict(RunResults=[rr])
+            for cb in callbacks:
+                written += cb.on_test_end(rr, model)
+            lo = hi
+        return written
+
     def write_metrics_csv(self, path):
         keys = []
         for m in self.metrics:
@@ -234,9 +257,19 @@ def do_training(args):
     print('Loading Validation Dataloader...')
     validation_loader = ShardedLoader(validation_dataset, args.batch_size, False, args.loaders, rank, world, args.seed)
 
+    if args.pretrained and not getattr(args, 'weights', None):
+        # upstream: pretrained=True downloads torchvision's ImageNet weights (neuston_models.py:23-42).  Training from random
+        # initialisation instead would silently change the experiment, so refuse.
+        raise SystemExit('TRAIN without --untrain fine-tunes ImageNet weights upstream (torchvision download); this path has no '
+                         'network and no torchvision: pass --weights <torchvision state_dict .pth> (or set '
+                         'IFCBK_PRETRAINED_WEIGHTS), or add --untrain to train from random initialisation')
     trainer = Trainer(args.emax, args.emin, args.estop, args.outdir, callbacks)
     hp = argparse.Namespace(**{k: v for k, v in vars(args).items()})
     classifier = NeustonModel(hp, device=int(os.environ.get('LOCAL_RANK', 0)), max_batch=args.batch_size)
+    if args.pretrained:
+        loaded, skipped = load_pretrained_weights(classifier.model, args.weights)
+        print('Loaded {} pretrained tensors from {}; freshly initialised: {}'.format(
+            len(loaded), args.weights, [k for k in skipped if not k.endswith('num_batches_tracked')]))
     eng = classifier.model.engine
     if eng.max_batch < args.batch_size:
         # --batch is per GPU as upstream (neuston_net.py:102); BatchNorm statistics are per step, so a step cannot be chunked
@@ -282,6 +315,13 @@ def do_run(args):
         args.SRC = args.SRC + os.sep
     if not args.outfile:
         args.outfile = ['D{BIN_YEAR}/D{BIN_DATE}/{BIN_ID}_class.h5'] if args.src_type == 'bin' else ['img_results.json']
+    if any(o.endswith('.h5') for o in args.outfile):
+        try:
+            import h5py  # noqa: F401
+        except ImportError:
+            raise SystemExit('RUN: outfile(s) {} need h5py, which is not installed in this environment (the default class file is '
+                             '.h5, neuston_net.py:181): install h5py or pass --outfile with a .mat / .json name'.format(
+                                 [o for o in args.outfile if o.endswith('.h5')]))
     callbacks = [SaveTestResults(outdir=args.outdir, outfile=o, timestamp=args.cmd_timestamp) for o in args.outfile]
     trainer = Trainer(0, 0, 0, args.outdir)
     filter_mode, filter_keywords = None, []
@@ -306,7 +346,11 @@ def do_run(args):
         else:
             dd = DataDirectory(os.path.dirname(args.SRC), whitelist=[os.path.basename(args.SRC)])
         error_bins = []
+        big = []          # --gobig: (bin pid, dataset) of every bin, classified together afterwards
+        n_bins = 0
         dist, rank, world = _dist()
+        if args.gobig:
+            print('Loading Bins', end=' ')
         for i, bin_fileset in enumerate(dd):
             if world > 1 and i % world != rank:        # RUN shards bins over ranks; no collective (replicas only)
                 continue
@@ -323,21 +367,37 @@ def do_run(args):
                 if all(os.path.isfile(o) for o in outs):
                     print('{} result-file(s) already exist - skipping this bin'.format(bin_obj))
                     continue
+            n_bins += 1
             try:
                 ds = IfcbBinDataset(bin_fileset, classifier.hparams.resize, classifier.hparams.img_norm)
                 if len(ds) == 0:
                     error_bins.append((bin_obj, AssertionError('Bin is Empty')))
+                    continue
+                if args.gobig:
+                    print('.', end='', flush=True)
+                    big.append((bin_obj, ds))
                     continue
                 loader = DataLoader(ds, batch_size=args.batch_size, pin_memory=True, num_workers=args.loaders,
                                     collate_fn=collate_rois)
                 trainer.test(classifier, loader, bin_obj, ds.transform, callbacks)
             except Exception as e:                     # noqa: per-bin isolation as upstream (:266-268)
                 error_bins.append((bin_obj, e))
+        if args.gobig and big:
+            # upstream hands Lightning the list of all bin loaders at once (:261-263,271).  Here "big" means what it buys on the
+            # GPU: ONE stream of full fixed-size batches across bin boundaries (a bin's tail no longer runs a short batch, the
+            # captured hipGraph of the batch size is replayed throughout); the scores are cut back per bin before the writers
+            print()
+            try:
+                trainer.test_many(classifier, big, args.batch_size, args.loaders, callbacks)
+            except Exception as e:                     # noqa
+                error_bins.extend((b, e) for b, _ in big)
         print('RUN IS DONE')
         if error_bins:
             print('The following bins failed; they were not processed:')
             for bin_obj, err in error_bins:
                 print(bin_obj, type(err), err)
+            if n_bins and len(error_bins) >= n_bins:
+                raise SystemExit('RUN: every one of the {} bins failed'.format(n_bins))
     else:
         img_paths = []
         if os.path.isdir(args.SRC):
@@ -384,6 +444,7 @@ def argparse_nn_train(train_subparser):
     t.add_argument('TRAIN_ID', help='Training ID. This value is the default value used by --outdir and --model-id.')
     model = t.add_argument_group(title='Model Adjustments', description=None)
     model.add_argument('--untrain', dest='pretrained', default=True, action='store_false', help='If set, initializes MODEL ~without~ pretrained neurons. Default (unset) is pretrained')
+    model.add_argument('--weights', metavar='PATH', default=os.environ.get('IFCBK_PRETRAINED_WEIGHTS'), help='(MI355X path, additive) torchvision state_dict (.pth) standing in for the ImageNet weights the reference downloads when --untrain is not set; there is no network / torchvision here. Default: $IFCBK_PRETRAINED_WEIGHTS')
     model.add_argument('--img-norm', nargs=2, metavar=('MEAN', 'STD'), help='Normalize images by MEAN and STD. eg1: "0.667 0.161", eg2: "0.056,0.058,0.051 0.067,0.071,0.057"')
     data = t.add_argument_group(title='Dataset Adjustments', description=None)
     data.add_argument('--seed', default=0, type=int, help='Set a specific seed for deterministic output & dataset-splitting reproducability.')
@@ -405,6 +466,10 @@ def argparse_nn_train(train_subparser):
     out.add_argument('--args-log', metavar='ALOG', default='args.yml', help='Specify a human-readable yaml filename. Default is args.yml')
     out.add_argument('--onnx', action='store_true', help='Additionally output an onnx version of the model')
     out.add_argument('--results', dest='result_files', metavar=('FNAME', 'SERIES'), nargs='+', action='append', help='FNAME: validation-results filename or pattern ("{epoch}"); .json .h5 .mat.  SERIES: data to include.')
+    optim = t.add_argument_group(title='Optimization', description='(MI355X path, additive: upstream keeps these flags commented out, neuston_net.py:385-390; the defaults are its only behaviour, Adam(lr=0.001))')
+    optim.add_argument('--optimizer', default='Adam', choices=['Adam', 'SGD'], help='Select an optimizer. Default is Adam')
+    optim.add_argument('--learning-rate', default=0.001, type=float, help='Set a learning rate. Default is 0.001')
+    optim.add_argument('--momentum', default=0.0, type=float, help='SGD momentum. Default is 0')
     meta = t.add_argument_group(title='Metadata and Annotations')
     meta.add_argument('--dataset-id', help='Associate a dataset id label with this model')
     meta.add_argument('--notes', help='Add any kind of note to the trained model.')
@@ -444,7 +509,7 @@ def proc_outdir(args):
     if args.cmd_mode == 'TRAIN':
         args.outdir = args.outdir.format(TRAIN_DATE=run_date_str, TRAIN_ID=args.TRAIN_ID)
     elif args.cmd_mode == 'RUN':
-        hp = torch.load(args.MODEL, map_location='cpu', weights_only=False)['hyper_parameters']   # no model build
+        hp = load_checkpoint_file(args.MODEL)['hyper_parameters']   # no model build
         args.outdir = args.outdir.format(RUN_DATE=run_date_str, RUN_ID=args.RUN_ID, MODEL_ID=hp['model_id'])
 
 

@@ -275,7 +275,8 @@ enum {
     IFCBK_OP_ADAM, IFCBK_OP_MEMSET, IFCBK_OP_COPY2D, IFCBK_OP_DROPOUT_MASK, IFCBK_OP_CONV_FWD_AFFINE,
     IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
     IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE,
-    IFCBK_OP_CONV_FWD_AFFINE_SEG
+    IFCBK_OP_CONV_FWD_AFFINE_SEG,
+    IFCBK_OP_SGD             /* p: P, G, momentum buffer (nullable); i[0] = n; f: lr, momentum, weight decay, grad scale */
 };
 typedef struct {
     int32_t kind;

@@ -132,3 +132,71 @@ def _worker(rank, world, port, tmp):
 def test_ddp_protocol_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def _worker_engine_plan(rank, world, port):
+    """the REAL backward op list of inception_v3 (Engine(plan_only=True): the op tables the GPU runs, built on the host)
+    drives the bucket plan; the gradients come from the CPU oracle replica on this rank's shard"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.dp import run_overlapped
+    from ifcb_classifier_amd.engine import Engine
+    from oracle import tv_models
+    torch.set_num_threads(3)
+    nc = 7
+    eng = Engine(graph.build('inception_v3', nc), max_batch=2, plan_only=True)
+    pl = eng.plan(2)
+    segs = eng.ddp_segments(pl)
+    ops = pl.bwd_list.ops
+    # the segments partition the backward list in order and their buckets tile the flat buffer from the tail
+    assert segs[0][0].n + sum(s[0].n for s in segs[1:]) == len(ops)
+    prev_lo, done = eng.nparam_padded, 0
+    for prog, b1, lo, hi in segs:
+        assert hi == prev_lo and lo < hi and b1 == done + prog.n
+        prev_lo, done = lo, b1
+    assert prev_lo == 0 and done == len(ops)
+    assert segs[-1][3] - segs[-1][2] <= eng.nparam_padded / 20      # the exposed last bucket is the small stem end
+    key_at = {o: key for key, (o, n, shape, kind, node) in eng.poff.items()}
+    torch.manual_seed(0)
+    model = tv_models.get_namebrand_model('inception_v3', nc, storage='fp32')
+    model.train()
+    g = torch.Generator().manual_seed(7)
+    X = torch.rand(2 * world, 3, 299, 299, generator=g)
+    Y = torch.randint(0, nc, (2 * world,), generator=g)
+    model.dropout_mask = torch.ones(2, 2048, dtype=torch.bool)
+
+    def grads_of(shard):
+        model.zero_grad()
+        out = model(X[shard::world])
+        (F.cross_entropy(out.logits, Y[shard::world]) + 0.4 * F.cross_entropy(out.aux_logits, Y[shard::world])).backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    mine = grads_of(rank)
+    filled = set()
+
+    def run_segment(seg):
+        b0 = seg[1] - seg[0].n
+        for k in range(b0, seg[1]):
+            for off in eng._op_param_offsets(ops[k]):
+                key = key_at[off]
+                eng.gviews[key].copy_(mine[key])              # what this backward op leaves in the flat gradient buffer
+                filled.add(key)
+
+    n = run_overlapped(segs, run_segment, eng.G, lambda t: dist.all_reduce(t, async_op=True))
+    assert n == len(segs) and filled == set(mine)
+    # emulation of "k shards, local BN statistics, mean of the gradients" (what the reference's ddp computes)
+    ref = {k: v / world for k, v in grads_of(0).items()}
+    for r in range(1, world):
+        for k, v in grads_of(r).items():
+            ref[k] += v / world
+    for key in ref:
+        assert torch.allclose(eng.gviews[key] / world, ref[key], rtol=1e-5, atol=1e-8), key
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_buckets_from_the_engines_own_backward_list_world2_gloo():
+    port = _free_port()
+    mp.spawn(_worker_engine_plan, args=(2, port), nprocs=2, join=True)

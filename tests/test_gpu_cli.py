@@ -124,3 +124,78 @@ def test_ddp_step_world1_equals_fused_step():
     torch.cuda.synchronize()
     assert len(calls) >= 2 and sum(calls) == eng.nparam_padded
     assert eng.loss.item() == l1 and torch.equal(eng.P, p1)
+
+
+def _make_bin(bdir, lid, n, seed):
+    rng = np.random.default_rng(seed)
+    blob, lines, off = b'', [], 0
+    for k in range(n):
+        h, w = (int(v) for v in rng.integers(20, 90, 2))
+        a = np.clip(rng.normal(96 if k % 2 else 160, 30, (h, w)), 0, 255).astype(np.uint8)
+        cols = ['0'] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(off)
+        lines.append(','.join(cols))
+        blob += a.tobytes()
+        off += h * w
+    (bdir / (lid + '.adc')).write_text('\n'.join(lines) + '\n')
+    (bdir / (lid + '.roi')).write_bytes(blob)
+
+
+def test_checkpoint_layout_gobig_and_h5_preflight(tmp_path, capsys):
+    """f-2: the .ptl carries the [PL] 1.3.8 keys (optimizer_states in parameters() order, hparams_name/type) and restores the
+    optimizer; RUN --gobig (one stream of full batches across bins, reference neuston_net.py:261-263,271) writes the same
+    per-bin files as the bin-at-a-time run; the default .h5 outfile fails fast when h5py is missing (ADVICE)."""
+    import argparse
+    from ifcb_classifier_amd.neuston_models import NeustonModel
+    hp = argparse.Namespace(MODEL='resnet18', classes=['a', 'b', 'c'], pretrained=False, batch_size=8, model_id='ck', resize=224,
+                            img_norm=None, seed=3, cmd_timestamp='2021-01-01T00:00:00+00:00')
+    torch.manual_seed(5)
+    m = NeustonModel(hp)
+    x = torch.rand(8, 3, 224, 224).cuda()
+    y = torch.randint(0, 3, (8,)).cuda()
+    for _ in range(2):
+        m.fit_batch(x, y)
+    torch.cuda.synchronize()
+    ck = m.checkpoint_dict(epoch=1, global_step=2)
+    for key in ('state_dict', 'hyper_parameters', 'epoch', 'global_step', 'optimizer_states', 'callbacks', 'lr_schedulers',
+                'pytorch-lightning_version', 'hparams_name', 'hparams_type'):
+        assert key in ck, key
+    st = ck['optimizer_states'][0]
+    names = [k for k, _ in m.named_parameters()]
+    assert st['param_groups'][0]['params'] == list(range(len(names))) and st['param_groups'][0]['lr'] == 0.001
+    assert tuple(st['state'][0]['exp_avg'].shape) == (64, 3, 7, 7) and st['state'][0]['step'] == 2
+    # a torch Adam built over the module's parameters accepts it (what Lightning does on resume)
+    opt = torch.optim.Adam(m.parameters(), lr=0.001)
+    opt.load_state_dict(st)
+    path = str(tmp_path / 'ck.ptl')
+    torch.save(ck, path)
+    m2 = NeustonModel.load_from_checkpoint(path, max_batch=8)
+    e1, e2 = m.model.engine, m2.model.engine
+    assert torch.equal(e1.P, e2.P) and torch.equal(e1.M, e2.M) and torch.equal(e1.V, e2.V) and e2.step_count == 2
+    assert torch.equal(e1.RB, e2.RB)
+    m.fit_batch(x, y); m2.fit_batch(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.P, e2.P)                     # training resumes bit-identically from the file
+
+    # ---- RUN on two bins: bin-at-a-time vs --gobig
+    bdir = tmp_path / 'run-data' / 'D2013' / 'D20130526'
+    bdir.mkdir(parents=True)
+    lids = ['D20130526T092352_IFCB013', 'D20130526T101500_IFCB013']
+    _make_bin(bdir, lids[0], 11, 1)
+    _make_bin(bdir, lids[1], 7, 2)
+    outs = {}
+    for tag, extra in (('one', []), ('big', ['--gobig'])):
+        out = str(tmp_path / ('run_' + tag))
+        _cli(['--batch', '8', '--loaders', '0', 'RUN', str(tmp_path / 'run-data'), path, tag, '--outdir', out,
+              '--outfile', '{BIN_ID}_class.json'] + extra)
+        outs[tag] = [json.load(open(os.path.join(out, lid + '_class.json'))) for lid in lids]
+    for a, b in zip(outs['one'], outs['big']):
+        assert a['bin_id'] == b['bin_id'] and a['roi_numbers'] == b['roi_numbers']
+        assert np.allclose(np.array(a['output_scores']), np.array(b['output_scores']), atol=2e-3)
+    assert [len(o['roi_numbers']) for o in outs['big']] == [11, 7]
+    # ---- default outfile is .h5: without h5py the run refuses up front instead of failing bin by bin
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(SystemExit, match='h5py'):
+            _cli(['--batch', '8', '--loaders', '0', 'RUN', str(tmp_path / 'run-data'), path, 'h5', '--outdir', str(tmp_path / 'run_h5')])

@@ -387,3 +387,54 @@ def test_bn_stats_of_a_stored_tensor(ctx, N, Cc, H, W, ld, dtype):
     for r in range(rows):       # every partial row covers exactly its 1024 rows
         blk = xs[r * 1024:(r + 1) * 1024]
         assert torch.allclose(part[r, 0].double().cpu(), blk.sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_sgd_matches_torch_sgd_over_steps(ctx):
+    """additive --optimizer SGD (north_star "SGD/Adam step"; upstream only has Adam): torch.optim.SGD's update with and
+    without momentum, and the fused engine step that reaches it through IFCBK_OP_SGD"""
+    from ifcb_classifier_amd import _lib
+    n = 70001
+    for mu in (0.0, 0.9):
+        g = torch.Generator().manual_seed(1)
+        p = torch.randn(n, generator=g)
+        pd, mom = p.clone().cuda(), torch.zeros(n).cuda()
+        pr = p.clone().requires_grad_(True)
+        opt = torch.optim.SGD([pr], lr=0.05, momentum=mu)
+        for step in range(4):
+            gr = torch.randn(n, generator=g)
+            ctx.call('ifcbk_sgd_flat', _lib.ptr(pd), _lib.ptr(gr.cuda()), _lib.ptr(mom) if mu else None, n, 0.05, mu, 0.0, 1.0,
+                     _lib.cur_stream())
+            pr.grad = gr.clone()
+            opt.step()
+        torch.cuda.synchronize()
+        assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6, mu
+    # the engine's fused step with optimizer='sgd' == its own gradients applied by torch.optim.SGD
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    eng = Engine(graph.build('resnet18', 3), 0, max_batch=4, optimizer='sgd', lr=0.01, momentum=0.9)
+    eng.init_weights(seed=2)
+    ref = eng.P.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9)
+    gg = torch.Generator().manual_seed(3)
+    for step in range(2):
+        x = torch.rand(4, 3, 224, 224, generator=gg).cuda()
+        eng.load_input_nchw(x)
+        eng.target[:4].copy_(torch.tensor([0, 1, 2, 1]))
+        with torch.no_grad():
+            ref.copy_(eng.P)                      # same starting point each step: compares ONE update, not a trajectory
+        mom_before = eng.M.clone()
+        eng.train_step(4)
+        torch.cuda.synchronize()
+        if step:
+            opt.state[ref]['momentum_buffer'] = mom_before.clone()
+        ref.grad = eng.G.clone()
+        opt.step()
+        assert (eng.P - ref.detach()).abs().max().item() < 1e-6
+    names = set()
+    import ctypes as CC
+    buf = CC.create_string_buffer(64)
+    pl = eng.plan(4)
+    for k in range(pl.step.n):
+        eng.ctx.lib.ifcbk_op_kernel(CC.byref(pl.step.arr[k]), buf, 64)
+        names.add(buf.value)
+    assert b'sgd_kernel' in names and b'adam_kernel' not in names

@@ -1,0 +1,113 @@
+"""Host-side logic that needs no GPU: the tolerant ``.ptl`` reader (f-2), the additive CLI flags, the RUN-mode pre-flight
+checks and the C-ABI surface (every symbol of include/ifcbk.h resolves; no compute call is made)."""
+import argparse
+import os
+import re
+import sys
+import types
+
+import pytest
+import torch
+
+
+def test_reference_style_checkpoint_loads_without_lightning(tmp_path):
+    """a [PL] 1.3.8 checkpoint keys ``callbacks`` by callback CLASS objects and stores ``hyper_parameters`` as an
+    AttributeDict: reading it must not need pytorch_lightning (SURVEY §5 hazard, reference neuston_net.py:173,443)"""
+    from ifcb_classifier_amd.neuston_models import load_checkpoint_file
+    pl = types.ModuleType('pytorch_lightning')
+    cb = types.ModuleType('pytorch_lightning.callbacks')
+    es = types.ModuleType('pytorch_lightning.callbacks.early_stopping')
+    ut = types.ModuleType('pytorch_lightning.utilities')
+    pa = types.ModuleType('pytorch_lightning.utilities.parsing')
+
+    class EarlyStopping:
+        pass
+    EarlyStopping.__module__ = es.__name__
+    EarlyStopping.__qualname__ = 'EarlyStopping'
+
+    class AttributeDict(dict):
+        pass
+    AttributeDict.__module__ = pa.__name__
+    AttributeDict.__qualname__ = 'AttributeDict'
+    es.EarlyStopping, pa.AttributeDict = EarlyStopping, AttributeDict
+    mods = {m.__name__: m for m in (pl, cb, es, ut, pa)}
+    sys.modules.update(mods)
+    try:
+        hp = AttributeDict(MODEL='resnet18', classes=['a', 'b'], pretrained=True, model_id='m1', resize=224, img_norm=None, seed=7)
+        ck = {'epoch': 3, 'global_step': 40, 'pytorch-lightning_version': '1.3.8',
+              'callbacks': {EarlyStopping: {'wait_count': 2, 'best_score': torch.tensor(0.5)}},
+              'optimizer_states': [{'state': {0: {'step': 40, 'exp_avg': torch.ones(2)}}, 'param_groups': [{'lr': 1e-3}]}],
+              'lr_schedulers': [], 'state_dict': {'model.fc.weight': torch.arange(6.).view(2, 3)}, 'hparams_name': 'hparams',
+              'hyper_parameters': hp}
+        path = str(tmp_path / 'ref.ptl')
+        torch.save(ck, path)
+    finally:
+        for k in mods:
+            del sys.modules[k]
+    with pytest.raises(Exception):
+        torch.load(path, map_location='cpu', weights_only=False)          # the plain reader needs Lightning
+    got = load_checkpoint_file(path)
+    assert dict(got['hyper_parameters']) == dict(hp) and got['epoch'] == 3
+    assert torch.equal(got['state_dict']['model.fc.weight'], ck['state_dict']['model.fc.weight'])
+    (cls, state), = got['callbacks'].items()
+    assert cls.__name__ == 'EarlyStopping' and state['wait_count'] == 2
+    assert got['optimizer_states'][0]['state'][0]['step'] == 40
+
+
+def test_additive_cli_flags_default_to_the_reference_behaviour():
+    from ifcb_classifier_amd import neuston_net as nn_
+    p = nn_.argparse_nn()
+    t = p.parse_args(['TRAIN', 'src', 'inception_v3', 'id1'])
+    assert (t.optimizer, t.learning_rate, t.momentum, t.precision) == ('Adam', 0.001, 0.0, 'bf16')
+    assert t.pretrained is True and t.weights == os.environ.get('IFCBK_PRETRAINED_WEIGHTS')
+    t = p.parse_args(['TRAIN', 'src', 'resnet18', 'id1', '--untrain', '--optimizer', 'SGD', '--learning-rate', '0.1', '--momentum', '0.9',
+                      '--weights', 'w.pth'])
+    assert (t.optimizer, t.learning_rate, t.momentum, t.pretrained, t.weights) == ('SGD', 0.1, 0.9, False, 'w.pth')
+    r = p.parse_args(['RUN', 'src', 'm.ptl', 'rid', '--gobig'])
+    assert r.gobig is True
+
+
+def test_train_refuses_pretrained_without_weights(tmp_path, monkeypatch):
+    """upstream's default (no --untrain) fine-tunes downloaded ImageNet weights; silently training from random init would
+    change the experiment (reference neuston_net.py:340, neuston_models.py:23)"""
+    from PIL import Image
+    import numpy as np
+    from ifcb_classifier_amd import neuston_net as nn_
+    monkeypatch.delenv('IFCBK_PRETRAINED_WEIGHTS', raising=False)
+    for cls in ('a', 'b'):
+        os.makedirs(tmp_path / 'src' / cls)
+        for i in range(4):
+            Image.fromarray(np.full((20, 30), 40 * i, np.uint8)).save(str(tmp_path / 'src' / cls / ('%s%d.png' % (cls, i))))
+    p = nn_.argparse_nn()
+    a = p.parse_args(['--loaders', '0', 'TRAIN', str(tmp_path / 'src'), 'resnet18', 'x', '--outdir', str(tmp_path / 'out')])
+    a.weights = None
+    nn_.argparse_nn_runtimeparams(a)
+    with pytest.raises(SystemExit, match='--weights'):
+        nn_.do_training(a)
+
+
+def test_header_and_binding_export_the_same_symbols():
+    from ifcb_classifier_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'ifcbk.h')).read()
+    declared = set(re.findall(r'\b(ifcbk_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = _lib.load()                          # every declared symbol resolves in the built library
+    assert lib.ifcbk_version().startswith(b'ifcbk')
+    assert 'IFCBK_OP_SGD' in hdr and _lib.OP_SGD == 30
+
+
+def test_schema_v1_bins_are_refused_not_silently_unstitched(monkeypatch):
+    """upstream classifies old-style bins through pyifcb's InfilledImages (neuston_data.py:446-449); raw halves would be a
+    different ROI set, so the dataset refuses unless told otherwise"""
+    import numpy as np
+    from ifcb_classifier_amd.ifcb_bins import Pid
+    from ifcb_classifier_amd.neuston_data import IfcbBinDataset
+    monkeypatch.delenv('IFCBK_ALLOW_UNSTITCHED_V1', raising=False)
+    b = types.SimpleNamespace(pid=Pid('IFCB1_2010_025_134132'), schema='v1', images={1: np.zeros((3, 4), np.uint8)})
+    with pytest.raises(NotImplementedError, match='stitching'):
+        IfcbBinDataset(b, 299)
+    monkeypatch.setenv('IFCBK_ALLOW_UNSTITCHED_V1', '1')
+    assert len(IfcbBinDataset(b, 299)) == 1
+    b2 = types.SimpleNamespace(pid=Pid('D20130526T092352_IFCB013'), schema='v2', images={2: np.zeros((3, 4), np.uint8)})
+    monkeypatch.delenv('IFCBK_ALLOW_UNSTITCHED_V1')
+    assert len(IfcbBinDataset(b2, 299)) == 1
