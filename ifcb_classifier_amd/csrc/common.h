@@ -150,6 +150,10 @@ int ifcbk_conv_rows_blocks(int N, int Pout);
 int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int W, int ldx, int P, int Q, int ldy, int pad_h,
                            int pad_w, const void* x, const void* w, void* y, float* part, const float* scale,
                            const float* shift, int relu, hipStream_t st);
+int ifcbk_num_cus();
+// conv_big.hip: wide-tile (256/320 pixels x 128..256 channels) ping-pong kernel; plan = does it serve this GEMM, and with which tile
+bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt, int* tn);
+int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* conv_args, int mt, int tn, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K, int M);
 bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg);     // the persistent warp-specialised kernel serves this GEMM shape
 int ifcbk_conv_fwd_wm(int M, int K);

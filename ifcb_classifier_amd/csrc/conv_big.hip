@@ -1,0 +1,317 @@
+// Wide-tile implicit-GEMM convolution (forward / stride-1 input gradient), bf16, for the big-M layers of a training step:
+// 256- or 320-pixel x 128..256-channel tiles, ONE 512-thread block per CU, eight waves as two GROUPS that run half a phase
+// apart ("ping-pong"): while the four waves of one group sit in their MFMA cluster, the four of the other group (their SIMD
+// partners: waves w and w+4 share a SIMD) read fragments from LDS and issue the next LDS-DMA pieces -- the matrix pipe and the
+// load path of every SIMD stay busy at the same time, which a lock-step block (every wave loads, then every wave multiplies)
+// cannot do with one block per CU.
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]     m = output pixel, n = output channel, k = (r,s,c); see conv_igemm.hip
+//
+// Geometry.  Wave w: group g = w >> 2 owns the pixel half [g*16*MT, (g+1)*16*MT) of the tile, column quarter wc = w & 3 owns
+// 16*TN channels: MT x TN accumulator tiles of 16x16 per wave (MT = 8 or 10: 256 / 320 pixels, TN = 2..4: 128..256 channels).
+// A K-tile (64 k) is consumed in NPH = MT/2 PHASES of two pixel tiles x TN channel tiles x 2 k-halves = 4*TN MFMAs.
+// A 320-pixel tile exists for the 17x17 maps: 256 images x 289 pixels = 73,984 rows are 289 tiles of 256 (a second, nearly
+// empty round on 256 CUs) but 232 tiles of 320 -- one round.
+//
+// LDS ring, in units the phases consume.  Pixel operand: 2*NPH slots of 64 rows x 128 B (32 rows of each group's half = what
+// ONE phase reads); slot of phase h = h mod 2*NPH; its 8 LDS-DMA pieces (1 KiB = 8 rows each) are issued by the 8 waves LA = 4
+// phases ahead.  Filter operand: two K-tile buffers of BN rows; a K-tile's TN*8 pieces are issued one per wave and phase,
+// LB = TN + 2 .. 3 phases ahead, and read into registers once, in the K-tile's first phase.  Every phase each wave issues its
+// 1-2 pieces, then waits with a COUNTED vmcnt that leaves the pieces of the last ~2.5 phases in flight, then meets the barrier.
+//
+// Ordering (physical barriers are numbered; group 1 executes one extra barrier up front, group 0 one at the end):
+//   group 0:  load(g) | #2g | mfma(g) | #2g+1 | load(g+1) ...        group 1:  #2g | load(g) | #2g+1 | mfma(g) | #2g+2 ...
+//   RAW: a piece read in load(g+1) was waited for (vmcnt) at the end of load(g) by the wave that issued it, i.e. before #2g
+//        (group 0) / #2g+1 (group 1); the earliest reader (group 0, after #2g+1) has passed both.
+//   WAR: a slot read in load(g) is re-filled by pieces issued in load(h), h >= g + 2: the latest reader (group 1) has its
+//        fragments in registers (lgkmcnt(0)) right after #2g+1, the earliest writer (group 0 in load(g+2)) starts after #2g+3.
+// Fragment reads are inline-asm ds_read_b128 (the compiler orders every LDS access it can see behind ALL pending LDS-DMA,
+// which would drain the ring every phase); their lgkmcnt(0) sits behind the barrier, in front of the MFMA cluster.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+template <int TN, int MT>
+struct BigCfg {
+    static constexpr int NPH = MT / 2;               // phases per K-tile
+    static constexpr int LA = 4;                     // pixel pieces: issued LA phases ahead of the phase that reads them
+    static constexpr int LB = TN + 2;                // filter pieces of a K-tile: piece p issued at (K-tile start) - LB + p
+    static_assert(MT % 2 == 0 && NPH >= 4 && LB <= 2 * NPH - 2 && TN <= NPH, "ring too shallow for this tile");
+    // loads one wave issues in phase x (any integer): its pixel piece + a filter piece in TN of the NPH phases
+    static constexpr int nld(int x) {
+        x = ((x % NPH) + NPH) % NPH;
+        return 1 + (((x + LB) % NPH) < TN ? 1 : 0);
+    }
+    // vmcnt at the end of load(J): everything read in load(J+1) has landed.  Pixel piece of phase J+1: issued in phase
+    // J+1-LA as the LAST load of that phase.  Filter pieces (needed when J+1 starts a K-tile): the last one was issued in
+    // phase J-2 as the FIRST load of that phase.
+    static constexpr int vm(int J) {
+        int a = 0;
+        for (int x = J + 2 - LA; x <= J; ++x) a += nld(x);
+        if ((J + 1) % NPH == 0) {
+            int b = 1 + nld(J - 1) + nld(J);
+            if (b < a) a = b;
+        }
+        return a;
+    }
+};
+
+#define BIG_DSREAD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+
+template <int TN, int MT, int MODE>
+__global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
+    typedef bf16_t T;
+    typedef BigCfg<TN, MT> Cfg;
+    constexpr int ES = 2, CE = 8, BK = 64;
+    constexpr int NPH = Cfg::NPH, LA = Cfg::LA, LB = Cfg::LB;
+    constexpr int HM = 16 * MT, BM = 2 * HM, BN = 64 * TN;
+    constexpr int NSLOT = 2 * NPH;
+    constexpr int ASLOT = 64 * BK * ES;               // bytes per pixel-operand slot
+    constexpr int BBUF = BN * BK * ES;                // bytes per filter K-tile buffer
+    constexpr int A_BYTES = NSLOT * ASLOT, RING_BYTES = A_BYTES + 2 * BBUF;
+    constexpr int LDC = BN + CE;
+    constexpr int CT_BYTES = BM * LDC * ES + 8 * BN * 2 * 4;
+    constexpr int SMEM_BYTES = RING_BYTES > CT_BYTES ? RING_BYTES : CT_BYTES;
+    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    T* sC = reinterpret_cast<T*>(smem);
+    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * ES);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = bid / a.tilesN, ntile = bid - mtile * a.tilesN;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // ---- LDS-DMA roles (as conv_igemm): one wave-instruction fills 8 tile rows; lane -> (row l>>3, physical chunk l&7);
+    // the XOR swizzle is applied on the source side; out-of-range offsets read zeros through the buffer descriptor
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int lrow8 = lane >> 3;
+    const int csrc = (lane & 7) ^ lrow8;
+    // pixel rows this lane gathers: one per phase-of-a-K-tile jp (slot rows 8*wave .. 8*wave+7 = this wave's own group)
+    int off0[NPH], bh[NPH], bw[NPH];
+    unsigned va[NPH];
+#pragma unroll
+    for (int jp = 0; jp < NPH; ++jp) {
+        const int m = m0 + grp * HM + 32 * jp + 8 * wc + lrow8;
+        const bool rv = m < a.M;
+        const int mm = rv ? m : 0;
+        const int n = (int)fdiv((uint32_t)mm, a.fPQ);
+        const int rem = mm - n * a.PQ;
+        const int p = (int)fdiv((uint32_t)rem, a.fQ);
+        const int q = rem - p * a.Q;
+        bh[jp] = rv ? p * a.ostr_h + a.base_h : -(1 << 24);
+        bw[jp] = q * a.ostr_w + a.base_w;
+        off0[jp] = ((n * a.H + bh[jp]) * a.W + bw[jp]) * a.ldx;
+        va[jp] = bh[jp] >= 0 ? (unsigned)(off0[jp] + csrc * CE) * (unsigned)ES : OOB;
+    }
+    int kc = csrc * CE, kr = 0, ks = 0;
+    while (kc >= a.C) {
+        kc -= a.C;
+        if (++ks == a.S) { ks = 0; ++kr; }
+    }
+    int tapoff = (kr * a.W + ks) * a.ldx + kc;
+    int ktA = 0;                                       // K-tile of the next pixel pieces
+    unsigned woff[TN];
+#pragma unroll
+    for (int p = 0; p < TN; ++p) {
+        const int n = n0 + p * 64 + wave * 8 + lrow8;
+        woff[p] = n < a.K ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
+    }
+    const int nk = (a.Kg + BK - 1) / BK;
+    const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
+    const bool plain = a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    const bool ktail_ok = (nk - 1) * BK + csrc * CE < a.Kg;
+
+    // the pixel piece of K-tile ktA, phase-in-tile JP, into slot (ktA & 1) * NPH + JP (rows 8*wave..)
+#define BIG_ISSUE_A(JP)                                                                                                   \
+    {                                                                                                                     \
+        unsigned char* dst = smem + ((ktA & 1) * NPH + (JP)) * ASLOT + wave * 8 * BK * ES;                                \
+        if (plain) {                                                                                                      \
+            const bool cut = ktA >= nk || (ktA == nk - 1 && !ktail_ok);                                                   \
+            lds_dma16(rsA, (lptr_t)dst, cut ? OOB : va[JP], ktA * 128);                                                   \
+        } else {                                                                                                          \
+            const int hr = bh[JP] + kr, wr = bw[JP] + ks;                                                                 \
+            const bool v = kr < a.R && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;                      \
+            const unsigned voff = v ? (unsigned)(off0[JP] + tapoff) * (unsigned)ES : OOB;                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff, 0, 0, 0);                                \
+        }                                                                                                                 \
+        if ((JP) == NPH - 1) {                                                                                            \
+            ++ktA;                                                                                                        \
+            if (!plain) {                                                                                                 \
+                kc += BK;                                                                                                 \
+                tapoff += BK;                                                                                             \
+                while (kc >= a.C) {                                                                                       \
+                    kc -= a.C;                                                                                            \
+                    tapoff += a.ldx - a.C;                                                                                \
+                    if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                                       \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+    // filter piece P (rows 64*P + 8*wave ..) of K-tile KT (chunks past Kg read the next row's head: the pixel operand is zero there)
+#define BIG_ISSUE_B(P, KT)                                                                                                \
+    {                                                                                                                     \
+        unsigned char* dst = smem + A_BYTES + ((KT) & 1) * BBUF + ((P) * 64 + wave * 8) * BK * ES;                         \
+        lds_dma16(rsB, (lptr_t)dst, woff[P], (KT) * 128);                                                                 \
+    }
+    // virtual phase G < 0: only issues what the steady state would have issued then
+#define BIG_PROLOGUE(G)                                                                                                   \
+    if constexpr (-(G) <= (LA > LB ? LA : LB)) {                                                                          \
+        if constexpr ((G) + LB >= 0 && (((G) + LB) % NPH) < TN) BIG_ISSUE_B(((G) + LB) % NPH, ((G) + LB) / NPH)           \
+        if constexpr ((G) + LA >= 0) BIG_ISSUE_A(((G) + LA) % NPH)                                                        \
+    }
+    BIG_PROLOGUE(-8) BIG_PROLOGUE(-7) BIG_PROLOGUE(-6) BIG_PROLOGUE(-5) BIG_PROLOGUE(-4) BIG_PROLOGUE(-3) BIG_PROLOGUE(-2) BIG_PROLOGUE(-1)
+    static_assert(LA <= 8 && LB <= 8, "prologue depth");
+
+    // ---- fragment addresses (LDS bytes): row = lane & 15 of a 16-row tile, 16-byte chunk (kk*4 + lane>>4) ^ (row & 7)
+    const int frow = lane & 15, fchunk = lane >> 4;
+    unsigned faA[2], faB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) * 16;
+        faA[kk] = (unsigned)(size_t)(lptr_t)(smem + (grp * 32 + frow) * BK * ES + ph);
+        faB[kk] = (unsigned)(size_t)(lptr_t)(smem + A_BYTES + (wc * 16 * TN + frow) * BK * ES + ph);
+    }
+
+    f32x4_t acc[MT][TN];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
+
+    bf16x8_t fb[TN][2];
+#define BIG_PHASE(J)                                                                                                      \
+    if constexpr ((J) < NPH) {                                                                                            \
+        bf16x8_t fa[2][2];                                                                                                \
+        if constexpr ((J) == 0) {                                                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) {                                                           \
+                BIG_DSREAD(fb[nt][0], bB0, nt * 16 * BK * ES);                                                            \
+                BIG_DSREAD(fb[nt][1], bB1, nt * 16 * BK * ES);                                                            \
+            }                                                                                                             \
+        }                                                                                                                 \
+        BIG_DSREAD(fa[0][0], bA0, (J) * ASLOT);                                                                           \
+        BIG_DSREAD(fa[0][1], bA1, (J) * ASLOT);                                                                           \
+        BIG_DSREAD(fa[1][0], bA0, (J) * ASLOT + 16 * BK * ES);                                                            \
+        BIG_DSREAD(fa[1][1], bA1, (J) * ASLOT + 16 * BK * ES);                                                            \
+        if constexpr ((((J) + LB) % NPH) < TN) BIG_ISSUE_B(((J) + LB) % NPH, kt + ((J) + LB) / NPH)                       \
+        BIG_ISSUE_A(((J) + LA) % NPH)                                                                                     \
+        wait_vmcnt<Cfg::vm(J)>();                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                     \
+        if constexpr ((J) == 0) {                                                                                         \
+            if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
+            if constexpr (TN == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
+            if constexpr (TN == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
+        } else {                                                                                                          \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]));         \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                  \
+            _Pragma("unroll") for (int ml = 0; ml < 2; ++ml)                                                              \
+                _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                         \
+                    acc[2 * (J) + ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[2 * (J) + ml][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                                     \
+        asm volatile("" ::: "memory");                                                                                    \
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned par = (unsigned)(kt & 1);
+        const unsigned bA0 = faA[0] + par * (NPH * ASLOT), bA1 = faA[1] + par * (NPH * ASLOT);
+        const unsigned bB0 = faB[0] + par * BBUF, bB1 = faB[1] + par * BBUF;
+        BIG_PHASE(0) BIG_PHASE(1) BIG_PHASE(2) BIG_PHASE(3) BIG_PHASE(4)
+    }
+    static_assert(NPH <= 5, "phase macro expansion");
+#undef BIG_PHASE
+#undef BIG_PROLOGUE
+#undef BIG_ISSUE_A
+#undef BIG_ISSUE_B
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // both groups have executed the same number of barriers
+    wait_vmcnt<0>();                                   // the tail's dummy pieces (K-tiles >= nk) have landed too
+    __syncthreads();                                   // the ring is dead: the epilogue reuses it as the C tile
+
+    // ---- epilogue: acc -> storage-type C tile in LDS (a lane holds 4 consecutive channels of one pixel per 16x16 tile)
+    {
+        const int g4 = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int m = grp * HM + mt * 16 + frow;
+                const int n = wc * (16 * TN) + nt * 16 + 4 * g4;
+                Mma<T>::pack4(sC + m * LDC + n, acc[mt][nt]);
+            }
+    }
+    __syncthreads();
+    conv_epilogue_store<T, BM, BN, 512, MODE>(a, sC, sRed, t, lane, wave, m0, n0, mtile);
+}
+
+// IFCBK_CONV_BIG: 0 = never, 1 = where the plan below expects a gain (default), 2 = wherever the kernel applies (tests force
+// it onto small shapes).  Read on every call -- a getenv per conv launch is noise next to the launch itself.
+int big_mode() {
+    const char* e = getenv("IFCBK_CONV_BIG");
+    return e ? atoi(e) : 1;
+}
+int big_force(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+template <int TN, int MT>
+void launch_big(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)(cdiv(a.M, 32 * MT) * a.tilesN)), block(512);
+    if (a.bs_raw) hipLaunchKernelGGL((conv_big<TN, MT, 3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_big<TN, MT, 0>), grid, block, 0, st, a);
+}
+
+}  // namespace
+
+// Tile choice for the wide-tile kernel; returns false when conv_igemm / conv_ws should serve the GEMM (M pixels, K output
+// channels, Kg reduction length).  One block per CU: the cost of a candidate is rounds x (phases per K-tile) x (MFMAs per
+// phase + a fixed part for the phase's loads and barriers); the grid must fill most of the chip.
+bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt_out, int* tn_out) {
+    if (big_mode() <= 0 || dtype != IFCBK_BF16) return false;
+    const int fmt = big_force("IFCBK_CONV_BIG_MT"), ftn = big_force("IFCBK_CONV_BIG_TN");
+    const int nk = cdiv(Kg, 64);
+    if (big_mode() < 2 && (nk < 4 || K < 96 || (int64_t)M < 192 * 256)) return false;
+    const int cus = ifcbk_num_cus();
+    double best = 0;
+    int bmt = 0, btn = 0;
+    for (int mt = 8; mt <= 10; mt += 2)
+        for (int tn = 2; tn <= 4; ++tn) {
+            if ((fmt && mt != fmt) || (ftn && tn != ftn)) continue;
+            if (mt == 10 && tn == 4) continue;                      // 160 accumulator registers: not built
+            const int64_t tiles = (int64_t)cdiv(M, 32 * mt) * cdiv(K, 64 * tn);
+            const double rounds = (double)cdiv(tiles, cus);
+            const double cost = rounds * (mt / 2) * (4.0 * tn + 6.0);
+            if (!bmt || cost < best) { best = cost; bmt = mt; btn = tn; }
+        }
+    if (!bmt) return false;
+    const int64_t tiles = (int64_t)cdiv(M, 32 * bmt) * cdiv(K, 64 * btn);
+    if (big_mode() < 2 && tiles < (3 * cus) / 4) return false;     // would leave a quarter of the chip idle
+    if (mt_out) *mt_out = bmt;
+    if (tn_out) *tn_out = btn;
+    return true;
+}
+
+int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_t st) {
+    ConvArgs& a = *reinterpret_cast<ConvArgs*>(args);
+    a.tilesN = cdiv(a.K, 64 * tn);
+    if (mt == 8 && tn == 2) launch_big<2, 8>(a, st);
+    else if (mt == 8 && tn == 3) launch_big<3, 8>(a, st);
+    else if (mt == 8 && tn == 4) launch_big<4, 8>(a, st);
+    else if (mt == 10 && tn == 2) launch_big<2, 10>(a, st);
+    else if (mt == 10 && tn == 3) launch_big<3, 10>(a, st);
+    else IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_big: no instantiation for mt=%d tn=%d", mt, tn);
+    IFCBK_LAUNCH_CHECK(ctx, "conv_big");
+    return 0;
+}

@@ -12,8 +12,8 @@
 static void segv_backtrace(int sig) {
     static const char head[] = "\n[ifcbk] fatal signal -- host backtrace:\n";
     (void)!write(2, head, sizeof(head) - 1);
-    void* frames[64];
-    const int n = backtrace(frames, 64);
+    void* frames[48];
+    const int n = backtrace(frames, 48);
     backtrace_symbols_fd(frames, n, 2);
     signal(sig, SIG_DFL);
     raise(sig);
@@ -26,9 +26,18 @@ static void maybe_install_backtrace() {
     if (!e || !atoi(e)) return;
     void* warm[4];
     (void)backtrace(warm, 4);          // loads libgcc now, not inside the handler
-    signal(SIGSEGV, segv_backtrace);
-    signal(SIGABRT, segv_backtrace);
-    signal(SIGBUS, segv_backtrace);
+    // on an alternate stack: a stack overflow (runaway recursion) must still be able to report itself
+    static char altstack[1 << 16];
+    stack_t ss;
+    ss.ss_sp = altstack; ss.ss_size = sizeof(altstack); ss.ss_flags = 0;
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = segv_backtrace;
+    sa.sa_flags = SA_ONSTACK | SA_NODEFER;
+    sigaction(SIGSEGV, &sa, nullptr);
+    sigaction(SIGABRT, &sa, nullptr);
+    sigaction(SIGBUS, &sa, nullptr);
 }
 
 extern "C" const char* ifcbk_version(void) { return "ifcbk 0.1 (gfx950, bf16 MFMA)"; }
@@ -385,6 +394,12 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
+            int bmt = 0, btn = 0;
+            const bool rows = ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]);
+            if (!rows && ifcbk_conv_big_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, &bmt, &btn)) {
+                snprintf(name, cap, "conv_big<%d, %d, 0>", btn, bmt);
+                break;
+            }
             if (ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]))
                 snprintf(name, cap, "conv_rows3x3<%d, %d>", d.C, d.K);
             else if (!(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]) && ifcbk_conv_ws_shape(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C))
@@ -402,6 +417,11 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                     break;
                 }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
+                int bmt = 0, btn = 0;
+                if (!s2 && ifcbk_conv_big_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, &bmt, &btn)) {
+                    snprintf(name, cap, "conv_big<%d, %d, %d>", btn, bmt, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
+                    break;
+                }
                 if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && !s2 && ifcbk_conv_ws_shape(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K)) {
                     snprintf(name, cap, "conv_ws<%d>", ifcbk_conv_fwd_nt(d.C, d.N * d.H * d.W));
                     break;
