@@ -29,6 +29,7 @@
 // which would drain the ring every phase); their lgkmcnt(0) sits behind the barrier, in front of the MFMA cluster.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
 #define BIG_ISSUE_B(P, KT)                                                                                                \
     {                                                                                                                     \
         unsigned char* dst = smem + A_BYTES + ((KT) & 1) * BBUF + ((P) * 64 + wave * 8) * BK * ES;                         \
-        lds_dma16(rsB, (lptr_t)dst, woff[P], (KT) * 128);                                                                 \
+        /* K-tiles past the end are issued too (the counted waits assume a fixed number of pieces per phase) but read nothing: \
+           the scalar offset is not part of the descriptor's range check */                                               \
+        lds_dma16(rsB, (lptr_t)dst, (KT) < nk ? woff[P] : OOB, (KT) * 128);                                               \
     }
     // virtual phase G < 0: only issues what the steady state would have issued then
 #define BIG_PROLOGUE(G)                                                                                                   \
@@ -185,6 +188,9 @@ __global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // what phase 0 reads (pixel slot 0, the filter tile 0) has landed in every wave's share, and every wave knows it
+    wait_vmcnt<Cfg::vm(-1)>();
+    __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
 
     bf16x8_t fb[TN][2];
@@ -255,6 +261,272 @@ __global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
     conv_epilogue_store<T, BM, BN, 512, MODE>(a, sC, sRed, t, lane, wave, m0, n0, mtile);
 }
 
+// ---------------------------------------------------------------- two long phases per K-tile
+// Same ping-pong, coarser grain.  Measured on conv_big (loads dropped through zero-record descriptors): the operand traffic is
+// NOT what bounds it (6e 7x1: 52.8 us -> 48.0 us with both operands dropped) -- the half-phase between two barriers is as long
+// as the LOAD side needs (fragment reads, piece issue, address VALU, waits: ~400 cycles) while the MFMA side has only 4*TN
+// MFMAs (192-256 cycles) to set against it.  Here a K-tile has TWO phases, of PM0 and PM1 = MT - PM0 pixel tiles: 2*PM*TN
+// MFMAs (384-576 cycles) per half-phase against about the same load work as before -- half the barriers per MFMA.
+//   phase 2T   (even): reads the filter fragments of K-tile T and the pixel tiles [0, PM0); issues the EVEN pixel slot and the
+//                      filter pieces of K-tile T+1 (PM0/2 + TN pieces per wave); then vmcnt(PM0/2 + TN): the odd slot of T is in
+//   phase 2T+1 (odd):  reads pixel tiles [PM0, MT); issues the ODD pixel slot of K-tile T+1 (PM1/2 pieces); then vmcnt(PM1/2)
+// Slots are double-buffered by K-tile parity; every slot is re-filled two phases after its last read (WAR rule of conv_big).
+template <int TN, int MT, int PM0, int MODE>
+__global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
+    typedef bf16_t T;
+    constexpr int ES = 2, CE = 8, BK = 64;
+    constexpr int PM1 = MT - PM0;
+    static_assert(PM0 % 2 == 0 && PM1 % 2 == 0 && PM0 > 0 && PM1 > 0, "whole pieces per wave");
+    constexpr int PMX = PM0 > PM1 ? PM0 : PM1;
+    constexpr int NA0 = PM0 / 2, NA1 = PM1 / 2;           // pixel pieces per wave in the even / odd phase
+    constexpr int HM = 16 * MT, BM = 2 * HM, BN = 64 * TN;
+    constexpr int ROWB = BK * ES;                          // 128 bytes per tile row
+    constexpr int E_BYTES = 2 * PM0 * 16 * ROWB, O_BYTES = 2 * PM1 * 16 * ROWB;      // even / odd pixel slot
+    constexpr int APAR = E_BYTES + O_BYTES;                // pixel bytes per K-tile parity (= BM rows)
+    constexpr int BBUF = BN * ROWB;
+    constexpr int A_BYTES = 2 * APAR, RING_BYTES = A_BYTES + 2 * BBUF;
+    constexpr int LDC = BN + CE;
+    constexpr int CT_BYTES = BM * LDC * ES + 8 * BN * 2 * 4;
+    constexpr int SMEM_BYTES = RING_BYTES > CT_BYTES ? RING_BYTES : CT_BYTES;
+    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    T* sC = reinterpret_cast<T*>(smem);
+    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * ES);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = bid / a.tilesN, ntile = bid - mtile * a.tilesN;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int lrow8 = lane >> 3;
+    const int csrc = (lane & 7) ^ lrow8;
+    // pixel rows of this lane: piece i of the even slot = slot rows 8*(wave + 8*i) .., likewise the odd slot
+    constexpr int NPX = NA0 + NA1;
+    int off0[NPX], bh[NPX], bw[NPX];
+    unsigned va[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const bool odd = i >= NA0;
+        const int pm = odd ? PM1 : PM0;
+        const int srow = 8 * (wave + 8 * (odd ? i - NA0 : i)) + lrow8;       // row inside the slot: [half][pm*16]
+        const int half = srow / (16 * pm), rr = srow - half * 16 * pm;
+        const int m = m0 + half * HM + (odd ? 16 * PM0 : 0) + rr;
+        const bool rv = m < a.M;
+        const int mm = rv ? m : 0;
+        const int n = (int)fdiv((uint32_t)mm, a.fPQ);
+        const int rem = mm - n * a.PQ;
+        const int p = (int)fdiv((uint32_t)rem, a.fQ);
+        const int q = rem - p * a.Q;
+        bh[i] = rv ? p * a.ostr_h + a.base_h : -(1 << 24);
+        bw[i] = q * a.ostr_w + a.base_w;
+        off0[i] = ((n * a.H + bh[i]) * a.W + bw[i]) * a.ldx;
+        va[i] = bh[i] >= 0 ? (unsigned)(off0[i] + csrc * CE) * (unsigned)ES : OOB;
+    }
+    int kc = csrc * CE, kr = 0, ks = 0;
+    while (kc >= a.C) {
+        kc -= a.C;
+        if (++ks == a.S) { ks = 0; ++kr; }
+    }
+    int tapoff = (kr * a.W + ks) * a.ldx + kc;
+    int ktA = 0;                                       // K-tile of the next pixel pieces
+    unsigned woff[TN];
+#pragma unroll
+    for (int p = 0; p < TN; ++p) {
+        const int n = n0 + p * 64 + wave * 8 + lrow8;
+        woff[p] = n < a.K ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
+    }
+    const int nk = (a.Kg + BK - 1) / BK;
+    const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
+    const bool plain = a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    const bool ktail_ok = (nk - 1) * BK + csrc * CE < a.Kg;
+
+    // pixel pieces [I0, I0+CNT) of K-tile ktA (even slot: I0 = 0, odd: I0 = NA0) into their slot rows
+#define PP_ISSUE_A(I0, CNT, SLOT_OFF)                                                                                     \
+    {                                                                                                                     \
+        unsigned char* slot = smem + (ktA & 1) * APAR + (SLOT_OFF);                                                       \
+        const bool kvalid = kr < a.R;                                                                                     \
+        const bool cut = ktA >= nk || (ktA == nk - 1 && !ktail_ok);                                                       \
+        _Pragma("unroll") for (int i = 0; i < (CNT); ++i) {                                                               \
+            unsigned char* dst = slot + (wave + 8 * i) * 8 * ROWB;                                                        \
+            if (plain) {                                                                                                  \
+                lds_dma16(rsA, (lptr_t)dst, cut ? OOB : va[(I0) + i], ktA * 128);                                         \
+            } else {                                                                                                      \
+                const int hr = bh[(I0) + i] + kr, wr = bw[(I0) + i] + ks;                                                 \
+                const bool v = kvalid && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;                    \
+                const unsigned voff = v ? (unsigned)(off0[(I0) + i] + tapoff) * (unsigned)ES : OOB;                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff, 0, 0, 0);                            \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+#define PP_ADVANCE_K()                                                                                                    \
+    {                                                                                                                     \
+        ++ktA;                                                                                                            \
+        if (!plain) {                                                                                                     \
+            kc += BK;                                                                                                     \
+            tapoff += BK;                                                                                                 \
+            while (kc >= a.C) {                                                                                           \
+                kc -= a.C;                                                                                                \
+                tapoff += a.ldx - a.C;                                                                                    \
+                if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                                           \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+#define PP_ISSUE_B(KT)                                                                                                    \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < TN; ++p) {                                                                  \
+            unsigned char* dst = smem + A_BYTES + ((KT) & 1) * BBUF + (p * 64 + wave * 8) * ROWB;                          \
+            lds_dma16(rsB, (lptr_t)dst, (KT) < nk ? woff[p] : OOB, (KT) * 128);                                           \
+        }                                                                                                                 \
+    }
+    // virtual phases -2 (even: K-tile 0's even slot + filter tile) and -1 (odd slot), then the first real wait + barrier
+    PP_ISSUE_A(0, NA0, 0)
+    PP_ISSUE_B(0)
+    PP_ISSUE_A(NA0, NA1, E_BYTES)
+    PP_ADVANCE_K()
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    unsigned faE[2], faO[2], faB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) * 16;
+        faE[kk] = (unsigned)(size_t)(lptr_t)(smem + (grp * 16 * PM0 + frow) * ROWB + ph);
+        faO[kk] = (unsigned)(size_t)(lptr_t)(smem + E_BYTES + (grp * 16 * PM1 + frow) * ROWB + ph);
+        faB[kk] = (unsigned)(size_t)(lptr_t)(smem + A_BYTES + (wc * 16 * TN + frow) * ROWB + ph);
+    }
+
+    f32x4_t acc[MT][TN];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    wait_vmcnt<NA1>();                                 // even slot + filter tile of K-tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
+
+    bf16x8_t fb[TN][2];
+    bf16x8_t fa[PMX][2];
+    const bool dbg_nomfma = a.dbg & 1, dbg_noread = a.dbg & 2, dbg_nodma = a.dbg & 4;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fb[i][0] = fb[i][1] = bf16x8_t{};
+#pragma unroll
+    for (int i = 0; i < PMX; ++i) fa[i][0] = fa[i][1] = bf16x8_t{};
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned par = (unsigned)(kt & 1);
+        // ================================================ even phase
+        {
+            const unsigned bB0 = faB[0] + par * BBUF, bB1 = faB[1] + par * BBUF;
+            const unsigned bA0 = faE[0] + par * APAR, bA1 = faE[1] + par * APAR;
+            if (!dbg_noread) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                if (nt == 0) { BIG_DSREAD(fb[0][0], bB0, 0); BIG_DSREAD(fb[0][1], bB1, 0); }
+                if (nt == 1) { BIG_DSREAD(fb[1][0], bB0, 16 * ROWB); BIG_DSREAD(fb[1][1], bB1, 16 * ROWB); }
+                if (nt == 2) { BIG_DSREAD(fb[2][0], bB0, 32 * ROWB); BIG_DSREAD(fb[2][1], bB1, 32 * ROWB); }
+                if (nt == 3) { BIG_DSREAD(fb[3][0], bB0, 48 * ROWB); BIG_DSREAD(fb[3][1], bB1, 48 * ROWB); }
+            }
+#pragma unroll
+            for (int ml = 0; ml < PM0; ++ml) {
+                if (ml == 0) { BIG_DSREAD(fa[0][0], bA0, 0); BIG_DSREAD(fa[0][1], bA1, 0); }
+                if (ml == 1) { BIG_DSREAD(fa[1][0], bA0, 16 * ROWB); BIG_DSREAD(fa[1][1], bA1, 16 * ROWB); }
+                if (ml == 2) { BIG_DSREAD(fa[2][0], bA0, 32 * ROWB); BIG_DSREAD(fa[2][1], bA1, 32 * ROWB); }
+                if (ml == 3) { BIG_DSREAD(fa[3][0], bA0, 48 * ROWB); BIG_DSREAD(fa[3][1], bA1, 48 * ROWB); }
+                if (ml == 4) { BIG_DSREAD(fa[4][0], bA0, 64 * ROWB); BIG_DSREAD(fa[4][1], bA1, 64 * ROWB); }
+                if (ml == 5) { BIG_DSREAD(fa[5][0], bA0, 80 * ROWB); BIG_DSREAD(fa[5][1], bA1, 80 * ROWB); }
+            }
+            }
+            if (!dbg_nodma) {
+            PP_ISSUE_A(0, NA0, 0)                       // K-tile kt+1 (ktA), even slot
+            PP_ISSUE_B(kt + 1)
+            }
+            wait_vmcnt<NA0 + TN>();                     // everything older than this phase's pieces: the odd slot of K-tile kt
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) asm volatile("" : "+v"(fb[nt][0]), "+v"(fb[nt][1]));
+#pragma unroll
+            for (int ml = 0; ml < PM0; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (!dbg_nomfma)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ml = 0; ml < PM0; ++ml)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[ml][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // ================================================ odd phase
+        {
+            const unsigned bA0 = faO[0] + par * APAR, bA1 = faO[1] + par * APAR;
+            if (!dbg_noread) {
+#pragma unroll
+            for (int ml = 0; ml < PM1; ++ml) {
+                if (ml == 0) { BIG_DSREAD(fa[0][0], bA0, 0); BIG_DSREAD(fa[0][1], bA1, 0); }
+                if (ml == 1) { BIG_DSREAD(fa[1][0], bA0, 16 * ROWB); BIG_DSREAD(fa[1][1], bA1, 16 * ROWB); }
+                if (ml == 2) { BIG_DSREAD(fa[2][0], bA0, 32 * ROWB); BIG_DSREAD(fa[2][1], bA1, 32 * ROWB); }
+                if (ml == 3) { BIG_DSREAD(fa[3][0], bA0, 48 * ROWB); BIG_DSREAD(fa[3][1], bA1, 48 * ROWB); }
+                if (ml == 4) { BIG_DSREAD(fa[4][0], bA0, 64 * ROWB); BIG_DSREAD(fa[4][1], bA1, 64 * ROWB); }
+                if (ml == 5) { BIG_DSREAD(fa[5][0], bA0, 80 * ROWB); BIG_DSREAD(fa[5][1], bA1, 80 * ROWB); }
+            }
+            }
+            if (!dbg_nodma) {
+            PP_ISSUE_A(NA0, NA1, E_BYTES)               // K-tile kt+1 (ktA), odd slot
+            }
+            PP_ADVANCE_K()
+            wait_vmcnt<NA1>();                          // the even slot and the filter tile of K-tile kt+1 have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ml = 0; ml < PM1; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (!dbg_nomfma)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ml = 0; ml < PM1; ++ml)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+                        acc[PM0 + ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[PM0 + ml][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_ADVANCE_K
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+    __syncthreads();
+    {
+        const int g4 = lane >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+                const int m = grp * HM + mt * 16 + frow;
+                const int n = wc * (16 * TN) + nt * 16 + 4 * g4;
+                Mma<T>::pack4(sC + m * LDC + n, acc[mt][nt]);
+            }
+    }
+    __syncthreads();
+    conv_epilogue_store<T, BM, BN, 512, MODE>(a, sC, sRed, t, lane, wave, m0, n0, mtile);
+}
+
 // IFCBK_CONV_BIG: 0 = never, 1 = where the plan below expects a gain (default), 2 = wherever the kernel applies (tests force
 // it onto small shapes).  Read on every call -- a getenv per conv launch is noise next to the launch itself.
 int big_mode() {
@@ -269,6 +541,12 @@ int big_force(const char* name) {
 template <int TN, int MT>
 void launch_big(const ConvArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(cdiv(a.M, 32 * MT) * a.tilesN)), block(512);
+    constexpr int PM0 = MT == 10 ? 4 : MT / 2;
+    if (big_force("IFCBK_CONV_BIG_NPH") != 5) {          // default: two long phases per K-tile; 5 = the fine-grained conv_big
+        if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 0>), grid, block, 0, st, a);
+        return;
+    }
     if (a.bs_raw) hipLaunchKernelGGL((conv_big<TN, MT, 3>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_big<TN, MT, 0>), grid, block, 0, st, a);
 }
@@ -279,15 +557,20 @@ void launch_big(const ConvArgs& a, hipStream_t st) {
 // channels, Kg reduction length).  One block per CU: the cost of a candidate is rounds x (phases per K-tile) x (MFMAs per
 // phase + a fixed part for the phase's loads and barriers); the grid must fill most of the chip.
 bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt_out, int* tn_out) {
-    if (big_mode() <= 0 || dtype != IFCBK_BF16) return false;
+    const int mode = big_mode();
+    if (mode <= 0 || dtype != IFCBK_BF16) return false;
     const int fmt = big_force("IFCBK_CONV_BIG_MT"), ftn = big_force("IFCBK_CONV_BIG_TN");
     const int nk = cdiv(Kg, 64);
-    if (big_mode() < 2 && (nk < 4 || K < 96 || (int64_t)M < 192 * 256)) return false;
+    // measured per layer at batch 256 (scripts/conv_big_check.py, interleaved rounds against conv_igemm): +20-25 % on the 17x17
+    // layers with 192 output channels (320 x 192 tiles: one round of 232 blocks instead of 578 on 512 slots), +7-25 % on the
+    // fused sibling 1x1 GEMMs (256 x 256); SLOWER with 128-channel tiles (0.7-0.9x) and on grids of many rounds (Conv2d_4a,
+    // 20 rounds: 0.83x -- one block per CU exposes every tile's prologue and epilogue, two co-resident blocks hide them)
+    if (mode < 2 && (nk < 4 || K < 136 || (int64_t)M < 192 * 256)) return false;
     const int cus = ifcbk_num_cus();
     double best = 0;
     int bmt = 0, btn = 0;
     for (int mt = 8; mt <= 10; mt += 2)
-        for (int tn = 2; tn <= 4; ++tn) {
+        for (int tn = (mode < 2 ? 3 : 2); tn <= 4; ++tn) {
             if ((fmt && mt != fmt) || (ftn && tn != ftn)) continue;
             if (mt == 10 && tn == 4) continue;                      // 160 accumulator registers: not built
             const int64_t tiles = (int64_t)cdiv(M, 32 * mt) * cdiv(K, 64 * tn);
@@ -297,7 +580,7 @@ bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt_out, int* tn_o
         }
     if (!bmt) return false;
     const int64_t tiles = (int64_t)cdiv(M, 32 * bmt) * cdiv(K, 64 * btn);
-    if (big_mode() < 2 && tiles < (3 * cus) / 4) return false;     // would leave a quarter of the chip idle
+    if (mode < 2 && (tiles < (3 * cus) / 4 || tiles > 6 * cus)) return false;
     if (mt_out) *mt_out = bmt;
     if (tn_out) *tn_out = btn;
     return true;
@@ -306,6 +589,15 @@ bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt_out, int* tn_o
 int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_t st) {
     ConvArgs& a = *reinterpret_cast<ConvArgs*>(args);
     a.tilesN = cdiv(a.K, 64 * tn);
+    // timing-only diagnostics (wrong results): a descriptor with zero records drops every load through it while the
+    // instruction stream, the waits and the barriers stay -- what does one operand's traffic cost?
+    if (const char* e = getenv("IFCBK_DEBUG_DROP")) {
+        if (strchr(e, 'a')) a.xbytes = 0;
+        if (strchr(e, 'b')) a.wbytes = 0;
+        if (strchr(e, 'm')) a.dbg |= 1;           // no MFMAs
+        if (strchr(e, 'r')) a.dbg |= 2;           // no fragment reads
+        if (strchr(e, 'd')) a.dbg |= 4;           // no LDS-DMA pieces
+    }
     if (mt == 8 && tn == 2) launch_big<2, 8>(a, st);
     else if (mt == 8 && tn == 3) launch_big<3, 8>(a, st);
     else if (mt == 8 && tn == 4) launch_big<4, 8>(a, st);

@@ -36,6 +36,7 @@ struct ConvArgs {
     int wKg, wSfull, w_rbase, w_sbase;      // filter row length (elements), full S, first tap row / column (step 2)
     int oH, oW, o_a, o_b;                   // dx dims and the class parity: output pixel (n,i,j) -> (n, 2i+o_a, 2j+o_b)
     fastdiv_t fPQ, fQ;
+    int dbg;                                // timing-only diagnostics of conv_big.hip (0 in production)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

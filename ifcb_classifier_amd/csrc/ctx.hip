@@ -240,7 +240,21 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
         const int L = op_lane(&ops[i]);
         const int wm = op_wait(&ops[i]) & used & ~(1 << L);
         for (int j = 0; j < IFCBK_MAX_LANES && !rc; ++j)
-            if (wm >> j & 1) rc = lane_order(c, st[L], st[j]);
+            if (wm >> j & 1) {
+                if (c->capturing && L != 0 && j != 0) {
+                    // Stream capture: an event wait between two FORKED streams makes each the other's "parallel capture
+                    // stream" inside the ROCm 7 runtime, and hipStreamEndCapture then recurses over that cycle until the stack
+                    // overflows (backtrace: an unexported libamdhip64 function at +0x2d3450 that walks a stream's capture
+                    // events, calls itself on every parallel stream and then clears the capture status -- Stream::EndCapture).
+                    // Edges between the origin stream and a forked stream are fine (every 2-lane capture is made of them), so
+                    // a lane-to-lane dependency is recorded as two of those: j -> origin -> L.  Over-constrains the origin
+                    // (lane 0 also waits for lane j), never under-constrains.
+                    rc = lane_order(c, st[0], st[j]);
+                    if (!rc) rc = lane_order(c, st[L], st[0]);
+                } else {
+                    rc = lane_order(c, st[L], st[j]);
+                }
+            }
         if (rc) break;
         c->ws = (char*)c->ws_base + (size_t)L * c->ws_bytes;
         const bool timed = ev && (!rec || (ops[i].flags & 0x80));      // run_program_ev brackets only ops with flags bit 7
@@ -320,7 +334,7 @@ extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, i
     if (int e = lane_resources(c, used)) return e;
     // one ordering event per fork / wait / join edge of this program (upper bound: 3 per op + 2 per lane)
     {
-        const int need = 3 * n + 2 * IFCBK_MAX_LANES;
+        const int need = 6 * n + 2 * IFCBK_MAX_LANES;      // (a lane-to-lane edge is recorded as two edges through the origin)
         if (c->n_cev < need) {
             hipEvent_t* ev = (hipEvent_t*)realloc(c->cev, sizeof(hipEvent_t) * need);
             if (!ev) IFCBK_FAIL(c, IFCBK_ENOMEM, "program_capture: event pool");
@@ -397,7 +411,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int bmt = 0, btn = 0;
             const bool rows = ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]);
             if (!rows && ifcbk_conv_big_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, &bmt, &btn)) {
-                snprintf(name, cap, "conv_big<%d, %d, 0>", btn, bmt);
+                snprintf(name, cap, "conv_pp2<%d, %d, %d, 0>", btn, bmt, bmt == 10 ? 4 : bmt / 2);
                 break;
             }
             if (ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]))
@@ -419,7 +433,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 int bmt = 0, btn = 0;
                 if (!s2 && ifcbk_conv_big_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, &bmt, &btn)) {
-                    snprintf(name, cap, "conv_big<%d, %d, %d>", btn, bmt, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
+                    snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
                     break;
                 }
                 if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && !s2 && ifcbk_conv_ws_shape(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K)) {

@@ -390,15 +390,14 @@ class Engine:
         except Exception:
             pass
         self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2' if dp else '4'))))
-        self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (hipGraph capture: <= 2, see replay)
+        self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (measured best)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
         # launch list (6.73 vs 6.85 ms); the train fwd+bwd graph is 4 % SLOWER (28.7 vs 27.6 ms per step: the graph's own
         # branch scheduling loses to the lane assignment below) -- so the default is 'eval'.  IFCBK_GRAPH=0 | eval | all
         gm = os.environ.get('IFCBK_GRAPH', 'eval')
-        # (capturing a 3- or 4-lane program crashes inside the ROCm 7.0 runtime -- a segfault in stream capture, not an error
-        # code; 2-lane captures are fine and are what the eval forward uses)
-        self.graph_eval = gm not in ('0', 'off', 'none') and self.NL_eval <= 2
-        self.graph_train = gm in ('1', 'all', 'train') and self.NL <= 2
+        # (any lane count can be captured: ctx.hip records lane-to-lane edges through the origin stream, see run_lanes)
+        self.graph_eval = gm not in ('0', 'off', 'none')
+        self.graph_train = gm in ('1', 'all', 'train')
         self.wgrad_side_lane = os.environ.get('IFCBK_WGRAD_SIDE', '0') != '0' and self.NL > 1
         self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
         max_raw = max(n.P * n.Q * n.K for n in self.convs)
@@ -1006,9 +1005,6 @@ class Engine:
         g = pl.graphs.get(name)
         if g is None:
             prog = getattr(pl, name)
-            if len(prog.lanes) > 2:
-                raise RuntimeError('hipGraph capture of a %d-lane program is not supported (the ROCm 7.0 runtime crashes in stream '
-                                   'capture with more than two forked streams): build the engine with IFCBK_LANES=2' % len(prog.lanes))
             g = pl.graphs[name] = self.ctx.capture(prog.arr, prog.n)
         self.ctx.graph_launch(g, self.stream())
 

@@ -56,7 +56,7 @@ def test_batch256_train_step_node_parity_with_production_dispatch():
     pl = eng.plan(B)
     names = _kernels(eng, pl.step)
     print('kernels of the batch-256 step:', sorted(names))
-    wide = [n for n in names if n.startswith('conv_big<') or n.startswith('conv_igemm<unsigned short, 6, 2, 2, 0>')]
+    wide = [n for n in names if n.startswith('conv_pp2<') or n.startswith('conv_big<') or n.startswith('conv_igemm<unsigned short, 6, 2, 2, 0>')]
     assert wide, 'no wide-tile implicit-GEMM kernel in the batch-256 dispatch'
     for must in ('conv_wgrad_rows<', 'conv_wgrad_stem', 'conv_rows3x3<', 'conv_ws<', 'bn_bwd', 'bn_apply_kernel'):
         assert _has(names, must), (must, sorted(names))
@@ -116,4 +116,4 @@ def test_batch256_eval_hipgraph_matches_oracle_on_a_subset():
         alone = hip(x[sub].cuda()).cpu()
     assert rel(alone, eh[sub]) < 0.5 * env + 2e-3
     names = _kernels(eng, eng.plan(B).fwd_eval)
-    assert _has(names, 'conv_igemm<') or _has(names, 'conv_big<')
+    assert _has(names, 'conv_igemm<') or _has(names, 'conv_pp2<')
