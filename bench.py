@@ -105,6 +105,85 @@ def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
                        % (steps, batch, dt))
 
 
+def run_mode_leg(args, local):
+    """BASELINE configs[3] / SURVEY 8(d) config 4: RUN-mode inference on 1 M synthetic IFCB ROIs, one GPU, fixed-size batches,
+    the eval forward replayed as a hipGraph.  Per batch: on-GPU PIL-exact resize + normalise of ragged u8 ROIs -> eval forward
+    (BatchNorm folded into the conv epilogues) -> softmax; file writing excluded.  The ROIs are windows of a pool of 8,192
+    distinct synthetic ROIs resident in HBM (1 M distinct ones would be 27 GB of host-generated random bytes; the kernels' work
+    does not depend on the pixel values).  Batch sweep on 100 k ROIs each, then the full count at the best batch size."""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    POOL, BMAX = 8192, 768
+    eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=BMAX)
+    eng.init_weights(seed=1234)
+    rois, _ = synth_rois(POOL + BMAX, 4321, eng.dev)
+
+    def run(B, n_rois):
+        nb = (n_rois + B - 1) // B
+        pl = eng.plan(B)
+
+        def batch(k):
+            s0 = (k * B) % POOL
+            eng.load_rois(rois['pixels'], rois['offs'][s0:s0 + B], rois['hs'][s0:s0 + B], rois['ws'][s0:s0 + B], rois['max_h'],
+                          rois['max_w'])
+            eng.forward_eval(B)
+            eng.run(pl.softmax)
+        for k in range(3):
+            batch(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nb):
+            batch(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return nb * B / dt, 1e3 * dt / nb, nb * B
+
+    sweep = {}
+    for B in (256, 512, 768):
+        ips, ms, n = run(B, 100000)
+        sweep[str(B)] = dict(images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), rois=n)
+    best = max(sweep, key=lambda b: sweep[b]['images_per_s'])
+    ips, ms, n = run(int(best), args.infer_rois)
+    tf = ips * 11.423e-3
+    return dict(workload='RUN-mode inference, inception_v3 %d-class bf16, %d synthetic ROIs h,w~U{32..299} (windows of a pool of %d '
+                         'in HBM), batch %s, hipGraph-replayed eval forward, preprocess + softmax included, file writes excluded '
+                         '(BASELINE.json configs[3])' % (args.classes, n, POOL, best),
+                images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), batch=int(best), rois=n, seconds=round(n / ips, 2),
+                batch_sweep_100k=sweep, hipgraph=bool(eng.graph_eval), program_lanes=eng.NL_eval,
+                roofline=dict(bound='mfma', achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                              frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flops_per_image=11.423e9,
+                              note='whole RUN step (preprocess + 94 convs with folded BatchNorm + pools + head + softmax) against the '
+                                   'dense bf16 MFMA peak; algorithmic flops = conv + fc MACs x 2 (SURVEY 8(d))'))
+
+
+def fp32_leg(args, local):
+    """the fp32 PARITY mode (fp32 storage, v_mfma_f32_16x16x4_f32: the mode that meets the north-star 1e-3 logit tolerance,
+    tests/test_gpu_model.py::test_fp32_*) timed on the same workload, so that nobody reads the bf16 speed with the fp32 parity"""
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    B = args.batch
+    eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=B, dtype='fp32')
+    if eng.max_batch < B:
+        return dict(skipped='batch %d exceeds the fp32 descriptor window (%d images)' % (B, eng.window_batch))
+    eng.init_weights(seed=1234)
+    rois, _ = synth_rois(B, 1234, eng.dev)
+    eng.target[:B].copy_(torch.randint(0, args.classes, (B,), generator=torch.Generator().manual_seed(99)))
+    for _ in range(2):
+        eng.load_rois(**rois)
+        eng.train_step(B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.fp32_steps):
+        eng.load_rois(**rois)
+        eng.train_step(B)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.fp32_steps
+    return dict(dtype='f32', ms_per_step=round(1e3 * dt, 2), images_per_s=round(B / dt, 1), steps=args.fp32_steps,
+                peak_tflops=157.3, frac_of_fp32_mfma_peak=round(B / dt * TRAIN_GFLOP_PER_IMG * 1e-3 / 157.3, 4),
+                note='parity mode: logits within 1e-3 of the fp32 CPU oracle (train 4e-5, eval 3e-7); the headline value is the bf16 mode, '
+                     'whose random-init logits sit inside the bf16-storage envelope of the oracle (DESIGN.md section 4)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -115,6 +194,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-events', action='store_true', help='do not record per-launch HIP events in the timed region')
     ap.add_argument('--dump-ops', default=None, help='write the per-op timing table (JSON) here')
+    ap.add_argument('--infer-rois', type=int, default=1000000, help='RUN-mode leg (BASELINE configs[3]): ROIs classified at the '
+                    'best batch size; 0 = the short leg only')
+    ap.add_argument('--fp32-steps', type=int, default=3, help='train steps of the fp32 parity mode timed next to the bf16 headline (0 = skip)')
     ap.add_argument('--train-only', action='store_true', help='skip the secondary RUN-mode (inference) measurement: '
                     'the process then launches training kernels only, so a rocprofv3 --stats summary of it is comparable '
                     'launch for launch with the per-kernel HIP-event times')
@@ -210,15 +292,8 @@ def main():
             eng.params_changed()
         survey = op_table(NS)
         conv = {k: v for k, v in survey.items() if k.startswith('conv_')}
-        # dominant kernel = the kernel TEMPLATE with the most time per step (conv_igemm / conv_wgrad_rows / ...), reported
-        # through its heaviest instantiation, which is the name rocprofv3 lists: two instantiations of different templates
-        # tie within 0.5 % (conv_igemm<..6,2,2,0> 2.88 vs conv_wgrad_rows<3> 2.90 ms), and a pick by instantiation alone
-        # flipped between runs
-        fam = {}
-        for k, v in conv.items():
-            fam[k.split('<')[0]] = fam.get(k.split('<')[0], 0.0) + v['ms']
-        top = max(fam, key=lambda f: fam[f])
-        dom = max((k for k in conv if k.split('<')[0] == top), key=lambda k: conv[k]['ms'])
+        # dominant kernel = the conv kernel instantiation (the name rocprofv3 lists) with the most time per step
+        dom = max(conv, key=lambda k: conv[k]['ms'])
         if use_ev:
             ev_dom = pl.step.timed([j for j in range(pl.step.n) if kernel_of(j) == dom])
     torch.cuda.synchronize()
@@ -288,17 +363,25 @@ def main():
             d = op_table(args.steps)[dom] if use_ev else survey[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None
-            try:        # HBM bytes per launch of the same kernel from the committed PMC passes (scripts/collect_traffic.py)
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1k_traffic.json')))['kernels']
-                traffic = round(tj[dom]['hbm_bytes_per_launch'])
-            except Exception:
-                pass
-            mfma_util = None
-            try:        # MFMA-pipe busy fraction of the same kernel from the committed PMC pass (scripts/collect_mfma.py)
-                mj = json.load(open(os.path.join(ROOT, 'profiles', 'r1k_mfma.json')))['kernels']
-                mfma_util = round(mj[dom]['mfma_pipe_utilisation'], 4)
-            except Exception:
-                pass
+            mfma_util, prof_src = None, None
+
+            def newest(suffix):
+                # the newest committed PMC summary (profiles/r<round><letter>_<suffix>.json) that lists this kernel
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s.json' % suffix)), reverse=True):
+                    try:
+                        k = json.load(open(f))['kernels']
+                        if dom in k:
+                            return k[dom], os.path.basename(f)
+                    except Exception:
+                        pass
+                return None, None
+            ent, src = newest('traffic')    # HBM bytes per launch from two separate --pmc passes (scripts/collect_traffic.py)
+            if ent:
+                traffic, prof_src = round(ent['hbm_bytes_per_launch']), src
+            ent, src = newest('mfma')       # MFMA-pipe busy fraction from its own --pmc pass (scripts/collect_mfma.py)
+            if ent:
+                mfma_util = round(ent['mfma_pipe_utilisation'], 4)
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                                'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches']),
@@ -310,7 +393,7 @@ def main():
                                if use_ev else 'N > 1: rank 0, untimed survey pass (3 local steps, every op bracketed, one lane)',
                                'isolated_tflops': round(survey[dom]['flops'] / (survey[dom]['ms'] * 1e-3) / 1e12, 2),
                                'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5),
-                               'pmc_mfma_pipe_utilisation': mfma_util}
+                               'pmc_mfma_pipe_utilisation': mfma_util, 'pmc_source': prof_src}
             if dom.startswith('conv_wgrad'):
                 # one weight-gradient op = the split-K MFMA kernel + its fixed-order fp32 reduction (wgrad_reduce): the event
                 # bracket, avg_launch_ms and achieved cover BOTH; rocprofv3 lists them as two kernels (their averages add up)
@@ -339,8 +422,15 @@ def main():
                                      ms=ms[j], gflop=fl.value / 1e9, mbytes=by.value / 1e6))
                 with open(args.dump_ops, 'w') as f:
                     json.dump(rows, f)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.train_only:
             del eng
+            torch.cuda.empty_cache()
+            if args.infer_rois > 0:
+                out['run_mode'] = run_mode_leg(args, local)
+            if args.fp32_steps > 0:
+                out['fp32_parity_mode'] = fp32_leg(args, local)
+        if world == 1 and not args.no_cpu_baseline:
+            eng = None
             torch.cuda.empty_cache()
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -154,6 +154,10 @@ int ifcbk_num_cus();
 // conv_big.hip: wide-tile (256/320 pixels x 128..256 channels) ping-pong kernel; plan = does it serve this GEMM, and with which tile
 bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt, int* tn);
 int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* conv_args, int mt, int tn, hipStream_t st);
+// conv_wgrad_pp.hip: wide-tile ping-pong weight gradient (plan: channel tile 32*kh, pixel splits)
+bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh, int* nsplit, int* split_len);
+int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
+                          int split_len, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K, int M);
 bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg);     // the persistent warp-specialised kernel serves this GEMM shape
 int ifcbk_conv_fwd_wm(int M, int K);

@@ -512,6 +512,15 @@ __global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     wait_vmcnt<0>();
     __syncthreads();
+    if (a.dbg & 8) {                                   // timing-only: no epilogue (one store keeps the accumulators alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) sacc += acc[mt][nt][0] + acc[mt][nt][3];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(a.y)[t] = sacc;
+        return;
+    }
     {
         const int g4 = lane >> 4;
 #pragma unroll
@@ -597,6 +606,7 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_
         if (strchr(e, 'm')) a.dbg |= 1;           // no MFMAs
         if (strchr(e, 'r')) a.dbg |= 2;           // no fragment reads
         if (strchr(e, 'd')) a.dbg |= 4;           // no LDS-DMA pieces
+        if (strchr(e, 'e')) a.dbg |= 8;           // no epilogue
     }
     if (mt == 8 && tn == 2) launch_big<2, 8>(a, st);
     else if (mt == 8 && tn == 3) launch_big<3, 8>(a, st);

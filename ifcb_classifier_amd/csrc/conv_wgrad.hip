@@ -731,10 +731,11 @@ int pick_mt(int K, int maxmt) {
     return best;
 }
 
-struct Plan { int mt, cols, stem, tilesM, tilesN, nsplit, split_len; size_t ws; };
+struct Plan { int mt, cols, stem, tilesM, tilesN, nsplit, split_len; size_t ws; int pp; };
 
 Plan make_plan(const ifcbk_conv_desc* d) {
     Plan p;
+    p.pp = 0;
     const int bkp = d->dtype == IFCBK_F32 ? F_BKP : BKP;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     int RSC = d->R * d->S * d->C;
@@ -765,6 +766,17 @@ Plan make_plan(const ifcbk_conv_desc* d) {
         p.split_len = 0;
         p.ws = (size_t)p.nsplit * d->K * RSC * sizeof(float);
         return p;
+    }
+    {
+        // wide-tile ping-pong kernel (conv_wgrad_pp.hip): 128..192 output channels x 256 columns per block, one block per CU
+        int kh = 0, ns = 0, len = 0;
+        if (ifcbk_wgrad_pp_plan(d, &kh, &ns, &len)) {
+            p.pp = kh; p.mt = -kh; p.cols = 0;
+            p.tilesM = cdiv(d->K, 32 * kh); p.tilesN = cdiv(RSC, 256);
+            p.nsplit = ns; p.split_len = len;
+            p.ws = (size_t)ns * d->K * RSC * sizeof(float);
+            return p;
+        }
     }
     p.tilesM = cdiv(d->K, 32 * p.mt);
     p.tilesN = cdiv(RSC, BNW);
@@ -852,6 +864,8 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
             case 3: hipLaunchKernelGGL(conv_wgrad_f32<3>, grid, block, 0, st, a); break;
             default: hipLaunchKernelGGL(conv_wgrad_f32<4>, grid, block, 0, st, a); break;
         }
+    } else if (p.pp) {
+        if (int e = ifcbk_wgrad_pp_launch(ctx, d, x, dy, (float*)ctx->ws, p.pp, p.nsplit, p.split_len, st)) return e;
     } else if (p.stem) {
         StemArgs sa;
         sa.x = x; sa.dy = dy; sa.slab = (float*)ctx->ws; sa.xbytes = a.xbytes; sa.dybytes = a.dybytes;

@@ -1,0 +1,347 @@
+// Convolution weight gradient, wide tile, ping-pong (bf16, gfx950) -- the structure of conv_big.hip applied to
+//   dW[k][j] = sum_pix dy[pix][k] * X[pix][j]        k = output channel, j = (r,s,c) filter column, X = gathered input
+// Block tile: (32*KH) output channels x 256 filter columns, 64 pixels per K-step, ONE 512-thread block per CU, split-K over pixel
+// ranges into fp32 slabs (summed in a fixed order by wgrad_reduce of conv_wgrad.hip).  conv_wgrad_rows moves 32 LDS-DMA pieces
+// per 0.79-1.05 M MACs (96..128 x 128 tiles, two blocks per CU) and sits at ~20 % MFMA utilisation; this tile moves 48-56
+// pieces per 2.1-3.1 M MACs.
+//
+// Eight waves = two groups (wave >> 2).  Group G owns the output-channel half [G*16*KH, (G+1)*16*KH) and column quarter
+// wc = wave & 3 (64 columns = 4 tiles): KH x 4 accumulator tiles per wave.  A K-step has two PHASES kh = 0, 1: the 32-pixel
+// halves of the step (one 16x16x32 MFMA per tile and phase).  The groups run half a phase apart (see conv_big.hip): while one
+// multiplies, the other reads fragments and issues LDS-DMA.
+//
+// LDS: two K-step buffers (step parity) of NSA + 4 sub-tiles [64 pixels][64 channels] (128-byte rows, 16-byte chunk c of row r
+// at physical chunk c ^ (r & 7), swizzle applied on the DMA source side).  Both operands are pixel-major, the reduction index is
+// the ROW: fragments come from ds_read_b64_tr_b16 (transposing read): lane (g, lq, lp) reads rows 4g+lq and 16+4g+lq of a
+// 32-pixel half, 4 channels at 4*lp -- a half-wave then touches 8 consecutive rows x 32 bytes = 16 distinct 16-byte slots.
+//
+// Staging.  Wave w loads pixel rows 8w..8w+7 of every sub-tile, i.e. rows of half G = w >> 2, read only in phases kh = G.
+// Its NP = NSA + 4 pieces of a step go out in two batches (P1 = ceil(NP/2), P2 = NP - P1) in consecutive phases:
+//     group 0:  (t,1) -> P1 of step t+2,   (t+1,0) -> P2 of step t+2        group 1:  (t,0) -> P1 of step t+1,  (t,1) -> P2 of step t+1
+// and the wave waits vmcnt(P1) at the end of the load part in which it issued a P1 batch: the step issued before is complete one
+// phase before its first reader.  WAR: a wave's fragment reads are COMPLETE (lgkmcnt(0)) before it meets the barrier that ends
+// its load part, so rows read in phase g may be re-filled from phase g+1 on (conv_big needs g+2: it waits behind the barrier).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct WppArgs {
+    const void* x;
+    const void* dy;
+    float* slab;      // [nsplit][K][RSC]
+    unsigned xbytes, dybytes;
+    int H, W, C, ldx;
+    int K, S;
+    int ldy;
+    int sh, sw, ph, pw;
+    int M, RSC;
+    int split_len;    // pixels per split (multiple of 64)
+    int tilesJ, tiles;
+    fastdiv_t fPQ, fQ;
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void wpp_dma16(__amdgpu_buffer_rsrc_t rs, lptr_t dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wpp_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#define WPP_TR(lo, hi, addr, OFF)                                                                                   \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                       \
+                 : "=&v"(lo), "=&v"(hi)                                                                             \
+                 : "v"(addr), "n"(OFF), "n"((OFF) + 16 * 128));
+
+// DM = 1: the LDS-DMA pieces are issued from INSIDE the MFMA cluster (one piece after each row of KH MFMAs) instead of the load
+// part: the matrix pipe leaves the wave's scalar / vector-memory issue ports idle half of the time, while the load part is what
+// bounds the ping-pong (conv_big.hip's measurements)
+template <int KH, int DM>
+__global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
+    constexpr int BMK = 32 * KH;                     // output channels per block
+    constexpr int NSA = (BMK + 63) / 64;             // dy sub-tiles
+    constexpr int NP = NSA + 4;                      // LDS-DMA pieces per wave and K-step
+    constexpr int P1 = (NP + 1) / 2, P2 = NP - P1;
+    constexpr int SUB = 64 * 128;                    // bytes per sub-tile
+    constexpr int PARB = NP * SUB;                   // bytes per K-step buffer
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARB];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / a.tiles;
+    const int tile = lin - split * a.tiles;
+    const int ktile = tile / a.tilesJ, jtile = tile - ktile * a.tilesJ;
+    const int k0 = ktile * BMK, j0 = jtile * 256;
+    const int pix_begin = split * a.split_len;
+    const int pix_end = min(pix_begin + a.split_len, a.M);
+    const int nsteps = (pix_end - pix_begin + 63) / 64;
+
+    // ---- LDS-DMA roles: lane -> (row 8*wave + (l>>3), physical chunk l&7), logical chunk (l&7) ^ (l>>3)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int FAR = 1 << 24;
+    const int lrow8 = lane >> 3;
+    const int csrc = (lane & 7) ^ lrow8;
+    unsigned acol[NSA];                              // byte offset of this lane's dy chunk inside a pixel row, or OOB
+#pragma unroll
+    for (int s = 0; s < NSA; ++s) {
+        const int ch = s * 64 + csrc * 8;
+        acol[s] = (ch < BMK && k0 + ch < a.K) ? (unsigned)(k0 + ch) * 2u : OOB;
+    }
+    int bcol_r[4], bcol_s[4], btap[4];               // filter tap (r, s) and byte offset of this lane's x chunk, per sub-tile
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int jcol = j0 + s * 64 + csrc * 8;
+        const bool bv = jcol < a.RSC;
+        const int jj = bv ? jcol : 0;
+        const int rs = jj / a.C;
+        const int c = jj - rs * a.C;
+        const int r = rs / a.S;
+        const int sx = rs - r * a.S;
+        bcol_r[s] = bv ? r : FAR;
+        bcol_s[s] = sx;
+        btap[s] = ((r * a.W + sx) * a.ldx + c) * 2;
+    }
+    // the pixel this lane gathers for the step its wave is staging
+    int ph0 = 0, pw0 = 0, pxoff = 0;
+    unsigned pdyoff = OOB;
+    int tgt = 0;                                     // step being staged
+#define WPP_DECODE()                                                                                                \
+    {                                                                                                               \
+        const int pix = pix_begin + tgt * 64 + wave * 8 + lrow8;                                                    \
+        const bool pv = tgt < nsteps && pix < pix_end;                                                              \
+        const uint32_t pp = pv ? (uint32_t)pix : 0u;                                                                \
+        const uint32_t n = fdiv(pp, a.fPQ);                                                                         \
+        const uint32_t rem = pp - n * a.fPQ.d;                                                                      \
+        const uint32_t p = fdiv(rem, a.fQ);                                                                         \
+        const uint32_t q = rem - p * a.fQ.d;                                                                        \
+        ph0 = pv ? (int)p * a.sh - a.ph : -FAR;                                                                     \
+        pw0 = (int)q * a.sw - a.pw;                                                                                 \
+        pxoff = (((int)n * a.H + ((int)p * a.sh - a.ph)) * a.W + pw0) * a.ldx * 2;                                  \
+        pdyoff = pv ? pp * (uint32_t)a.ldy * 2u : OOB;                                                              \
+    }
+    // piece I of the step `tgt`: I < NSA -> dy sub-tile I, else x sub-tile I - NSA
+#define WPP_PIECE(I)                                                                                                \
+    {                                                                                                               \
+        unsigned char* dst = smem + (tgt & 1) * PARB + (I) * SUB + wave * 1024;                                     \
+        if ((I) < NSA) {                                                                                            \
+            const unsigned vo = (pdyoff != OOB && acol[(I) < NSA ? (I) : 0] != OOB) ? pdyoff + acol[(I) < NSA ? (I) : 0] : OOB; \
+            wpp_dma16(rsA, (lptr_t)dst, vo);                                                                        \
+        } else {                                                                                                    \
+            constexpr int sb = (I) < NSA ? 0 : (I) - NSA;                                                           \
+            const bool v = (unsigned)(ph0 + bcol_r[sb]) < (unsigned)a.H && (unsigned)(pw0 + bcol_s[sb]) < (unsigned)a.W; \
+            wpp_dma16(rsB, (lptr_t)dst, v ? (unsigned)(pxoff + btap[sb]) : OOB);                                    \
+        }                                                                                                           \
+    }
+#define WPP_BATCH1()                                                                                                \
+    {                                                                                                               \
+        WPP_DECODE()                                                                                                \
+        WPP_PIECE(0) WPP_PIECE(1) WPP_PIECE(2)                                                                      \
+        if constexpr (P1 > 3) WPP_PIECE(3)                                                                          \
+    }
+#define WPP_BATCH2()                                                                                                \
+    {                                                                                                               \
+        WPP_PIECE(P1) WPP_PIECE(P1 + 1) WPP_PIECE(P1 + 2)                                                           \
+        ++tgt;                                                                                                      \
+    }
+    static_assert(P1 >= 3 && P1 <= 4 && P2 == 3, "batch macros");
+
+    // ---- prologue: step 0 completely; group 0 is one batch ahead (its first batch of step 1)
+    WPP_BATCH1() WPP_BATCH2()
+    if (grp == 0) WPP_BATCH1()
+
+    // ---- fragment addresses: tile-in-sub-tile ti (16 channels = chunks 2ti, 2ti+1); lane (g, lq, lp)
+    const int g = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
+    const int row0 = 4 * g + lq, rk = row0 & 7;
+    unsigned tiaddr[4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) tiaddr[ti] = (unsigned)(row0 * 128 + (((2 * ti + (lp >> 1)) ^ rk) * 16) + (lp & 1) * 8);
+    const unsigned sbase = (unsigned)(size_t)(lptr_t)smem;
+    unsigned xaddr[4], daddr[KH];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) xaddr[jt] = sbase + (NSA + wc) * SUB + tiaddr[jt];
+#pragma unroll
+    for (int kt = 0; kt < KH; ++kt) {
+        const int ch = grp * 16 * KH + kt * 16;
+        const int ti = (ch >> 4) & 3;
+        // (runtime select of the per-lane tile address: four candidates, wave-uniform ti)
+        const unsigned ta = ti == 0 ? tiaddr[0] : ti == 1 ? tiaddr[1] : ti == 2 ? tiaddr[2] : tiaddr[3];
+        daddr[kt] = sbase + (ch >> 6) * SUB + ta;
+    }
+
+    f32x4_t acc[4][KH];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < KH; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (grp == 0) wpp_wait_vmcnt<P1>(); else wpp_wait_vmcnt<0>();     // step 0 has landed (group 0: its step-1 batch may fly)
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
+
+// batch piece for MFMA-row slot SL of the phase (DM = 1): batch 1 = pieces [0, P1), batch 2 = pieces [P1, NP)
+#define WPP_SLOT(FIRST, SL)                                                                                         \
+    {                                                                                                               \
+        if (FIRST) {                                                                                                \
+            if ((SL) == 0) { WPP_DECODE() }                                                                         \
+            if ((SL) == 0) WPP_PIECE(0)                                                                             \
+            if ((SL) == 1) WPP_PIECE(1)                                                                             \
+            if ((SL) == 2) WPP_PIECE(2)                                                                             \
+            if constexpr (P1 > 3) { if ((SL) == 3) WPP_PIECE(3) }                                                   \
+        } else {                                                                                                    \
+            if ((SL) == 0) WPP_PIECE(P1)                                                                            \
+            if ((SL) == 1) WPP_PIECE(P1 + 1)                                                                        \
+            if ((SL) == 2) { WPP_PIECE(P1 + 2) ++tgt; }                                                             \
+        }                                                                                                           \
+    }
+#define WPP_PHASE(KHV)                                                                                              \
+    {                                                                                                               \
+        s16x4_t xlo[4], xhi[4], dlo[KH], dhi[KH];                                                                   \
+        _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) WPP_TR(xlo[jt], xhi[jt], xaddr[jt] + paroff, (KHV) * 32 * 128) \
+        _Pragma("unroll") for (int kt = 0; kt < KH; ++kt) WPP_TR(dlo[kt], dhi[kt], daddr[kt] + paroff, (KHV) * 32 * 128) \
+        if (DM) {                                                                                                   \
+            /* the step whose last pieces went out in the previous MFMA cluster must be complete before the next phase */ \
+            if (grp == ((KHV) == 1 ? 0 : 1)) wpp_wait_vmcnt<0>();                                                   \
+        } else if (grp == 0) {                                                                                      \
+            if ((KHV) == 1) { WPP_BATCH1() wpp_wait_vmcnt<P1>(); } else { WPP_BATCH2() }                            \
+        } else {                                                                                                    \
+            if ((KHV) == 0) { WPP_BATCH1() wpp_wait_vmcnt<P1>(); } else { WPP_BATCH2() }                            \
+        }                                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        /* reads complete BEFORE the barrier (WAR, see header) */ \
+        _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) asm volatile("" : "+v"(xlo[jt]), "+v"(xhi[jt]));          \
+        _Pragma("unroll") for (int kt = 0; kt < KH; ++kt) asm volatile("" : "+v"(dlo[kt]), "+v"(dhi[kt]));         \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        {                                                                                                           \
+            bf16x8_t fx[4], fd[KH];                                                                                 \
+            _Pragma("unroll") for (int jt = 0; jt < 4; ++jt)                                                        \
+                fx[jt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(xlo[jt], xhi[jt], 0, 1, 2, 3, 4, 5, 6, 7)); \
+            _Pragma("unroll") for (int kt = 0; kt < KH; ++kt)                                                       \
+                fd[kt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(dlo[kt], dhi[kt], 0, 1, 2, 3, 4, 5, 6, 7)); \
+            const bool first = grp == 0 ? (KHV) == 1 : (KHV) == 0;      /* which batch this group issues in this phase */ \
+            _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) {                                                      \
+                _Pragma("unroll") for (int kt = 0; kt < KH; ++kt)                                                   \
+                    acc[jt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[jt], fd[kt], acc[jt][kt], 0, 0, 0);    \
+                if (DM) {                                                                                           \
+                    __builtin_amdgcn_sched_barrier(0);                                                              \
+                    if (jt == 0) WPP_SLOT(first, 0)                                                                 \
+                    if (jt == 1) WPP_SLOT(first, 1)                                                                 \
+                    if (jt == 2) WPP_SLOT(first, 2)                                                                 \
+                    if (jt == 3) WPP_SLOT(first, 3)                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                              \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+    }
+
+    for (int st = 0; st < nsteps; ++st) {
+        const unsigned paroff = (unsigned)(st & 1) * PARB;
+        WPP_PHASE(0)
+        WPP_PHASE(1)
+    }
+#undef WPP_PHASE
+#undef WPP_SLOT
+#undef WPP_BATCH1
+#undef WPP_BATCH2
+#undef WPP_PIECE
+#undef WPP_DECODE
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wpp_wait_vmcnt<0>();                               // the tail's dummy pieces
+
+    // ---- slab store: lane holds 4 consecutive columns j of one output channel k per tile
+    float* out = a.slab + (size_t)split * a.K * a.RSC;
+    const int kl = lane & 15, jq = (lane >> 4) * 4;
+#pragma unroll
+    for (int kt = 0; kt < KH; ++kt) {
+        const int k = k0 + grp * 16 * KH + kt * 16 + kl;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = j0 + wc * 64 + jt * 16 + jq;
+            if (k < a.K && j < a.RSC) *reinterpret_cast<f32x4_t*>(out + (size_t)k * a.RSC + j) = acc[jt][kt];
+        }
+    }
+}
+
+int wpp_mode() {
+    const char* e = getenv("IFCBK_WGRAD_PP");
+    return e ? atoi(e) : 1;
+}
+
+}  // namespace
+
+// Plan: does the wide-tile kernel serve this weight gradient, with which channel tile (kh = 4, 5, 6: 128 / 160 / 192 output
+// channels per block), how many pixel splits.  One block per CU: the splits fill the chip once.
+bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh_out, int* nsplit_out, int* split_len_out) {
+    const int mode = wpp_mode();
+    if (mode <= 0 || d->dtype != IFCBK_BF16 || d->Cw != d->C) return false;
+    const int64_t M = (int64_t)d->N * d->P * d->Q;
+    const int RSC = d->R * d->S * d->C;
+    if (RSC % 4) return false;
+    if (mode < 2 && (d->K < 128 || RSC < 192 || M < 8192)) return false;
+    // channel tile: least padded work; ties -> the larger tile
+    int best = 0;
+    double bestc = 0;
+    for (int kh = 4; kh <= 6; ++kh) {
+        const double c = (double)cdiv(d->K, 32 * kh) * (32 * kh + 24);
+        if (!best || c < bestc - 1e-9 || (c < bestc + 1e-9 && kh > best)) { best = kh; bestc = c; }
+    }
+    if (const char* e = getenv("IFCBK_WGRAD_PP_KH")) { const int f = atoi(e); if (f >= 4 && f <= 6) best = f; }
+    const int tiles = cdiv(d->K, 32 * best) * cdiv(RSC, 256);
+    const int cus = ifcbk_num_cus();
+    const int64_t steps = (M + 63) / 64;
+    int64_t ns = cus / tiles;
+    const int64_t maxsplit = steps / 8 > 0 ? steps / 8 : 1;
+    if (ns > maxsplit) ns = maxsplit;
+    if (ns < 1) ns = 1;
+    // measured at batch 256 against conv_wgrad_rows (scripts/wgrad_pp_check.py, interleaved rounds, op = kernel + reduce):
+    // +4-13 % on the 17x17 layers with 192 output channels, +12 % Mixed_6a 3x3/s2, +31 % on the Mixed_7c sibling GEMM; SLOWER with
+    // 128-channel tiles (0.81x), with fewer than ~20 K-steps per split (8x8 1x3 / 3x1, Mixed_7a 3x3/s2: 0.90-0.94x) and when the
+    // grid leaves CUs idle.  Issuing the pieces from inside the MFMA cluster (DM = 1) was 5-10 % slower everywhere.
+    if (mode < 2 && (best < 5 || (int64_t)tiles * ns < (3 * cus) / 4 || steps / ns < 20)) return false;
+    const int64_t len = ((steps + ns - 1) / ns) * 64;
+    ns = (M + len - 1) / len;
+    *kh_out = best;
+    *nsplit_out = (int)ns;
+    *split_len_out = (int)len;
+    return true;
+}
+
+int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
+                          int split_len, hipStream_t st) {
+    WppArgs a;
+    const int es = 2;
+    a.x = x; a.dy = dy; a.slab = slab;
+    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es);
+    a.dybytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * es);
+    a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+    a.K = d->K; a.S = d->S; a.ldy = d->ldy;
+    a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.M = d->N * d->P * d->Q; a.RSC = d->R * d->S * d->C;
+    a.split_len = split_len;
+    a.tilesJ = cdiv(a.RSC, 256);
+    a.tiles = cdiv(d->K, 32 * kh) * a.tilesJ;
+    a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
+    const dim3 grid((unsigned)(a.tiles * nsplit)), block(512);
+    const char* e = getenv("IFCBK_WGRAD_PP_DM");
+    const int dm = e ? atoi(e) : 0;
+    if (kh == 4 && dm) hipLaunchKernelGGL((conv_wgrad_pp<4, 1>), grid, block, 0, st, a);
+    else if (kh == 5 && dm) hipLaunchKernelGGL((conv_wgrad_pp<5, 1>), grid, block, 0, st, a);
+    else if (kh == 6 && dm) hipLaunchKernelGGL((conv_wgrad_pp<6, 1>), grid, block, 0, st, a);
+    else if (kh == 4) hipLaunchKernelGGL((conv_wgrad_pp<4, 0>), grid, block, 0, st, a);
+    else if (kh == 5) hipLaunchKernelGGL((conv_wgrad_pp<5, 0>), grid, block, 0, st, a);
+    else if (kh == 6) hipLaunchKernelGGL((conv_wgrad_pp<6, 0>), grid, block, 0, st, a);
+    else IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_pp: kh=%d", kh);
+    IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_pp");
+    return 0;
+}

@@ -449,7 +449,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: {
             int mt = 0, cols = 0;
             ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
-            if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
+            if (mt < 0) snprintf(name, cap, "conv_wgrad_pp<%d>", -mt);
+            else if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
             else if (mt == 0) snprintf(name, cap, "conv_wgrad_stem");
             else if (cols) snprintf(name, cap, "conv_wgrad_cols<%d, 4>", mt);
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);

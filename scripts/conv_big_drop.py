@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc
-L = {'6e_7x1x': (256, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), '6e_7x1': (256, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), '6e_1x1g': (256, 768, 17, 17, 768, 1, 1, 1, 1, 0, 0),
+L = {'k64_7x1': (256, 64, 17, 17, 192, 7, 1, 1, 1, 3, 0), 'k64_1x1': (256, 64, 17, 17, 192, 1, 1, 1, 1, 0, 0), '6e_7x1': (256, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), '6e_1x1g': (256, 768, 17, 17, 768, 1, 1, 1, 1, 0, 0),
      '4a_3x3': (256, 80, 73, 73, 192, 3, 3, 1, 1, 0, 0), '5c_3x3b': (256, 96, 35, 35, 96, 3, 3, 1, 1, 1, 1)}
 ctx = _lib.Context(0); ctx.reserve(1 << 30); st = _lib.cur_stream()
 for name, (N, Cc, H, W, K, R, S, sh, sw, ph, pw) in L.items():
@@ -16,7 +16,7 @@ for name, (N, Cc, H, W, K, R, S, sh, sw, ph, pw) in L.items():
     flops = 2.0 * N * P * Q * K * R * S * Cc
     os.environ['IFCBK_CONV_BIG'] = '2'
     res = []
-    for drop in ('', 'ab', 'm', 'rd', 'mrd', 'r', 'd'):
+    for drop in ('', 'e', 'mrd', 'mrde', 'rd', 'rde', 'm', 'me'):
         os.environ['IFCBK_DEBUG_DROP'] = drop
         run = lambda: ctx.call('ifcbk_conv2d_fwd', C.byref(d), _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(part), st)
         run(); torch.cuda.synchronize()
