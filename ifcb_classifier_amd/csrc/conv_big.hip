@@ -551,6 +551,10 @@ template <int TN, int MT>
 void launch_big(const ConvArgs& a, hipStream_t st) {
     dim3 grid((unsigned)(cdiv(a.M, 32 * MT) * a.tilesN)), block(512);
     constexpr int PM0 = MT == 10 ? 4 : MT / 2;
+    if (a.seg_n) {                                       // eval-mode sibling GEMM: per-segment destinations (conv_epilogue_store MODE 4)
+        hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 4>), grid, block, 0, st, a);
+        return;
+    }
     if (big_force("IFCBK_CONV_BIG_NPH") != 5) {          // default: two long phases per K-tile; 5 = the fine-grained conv_big
         if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 0>), grid, block, 0, st, a);

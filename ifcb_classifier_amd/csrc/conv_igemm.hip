@@ -558,8 +558,7 @@ void launch_ws(const ConvArgs& a, hipStream_t st) {
 }
 
 // the wide-tile kernel serves plain gathers (forward of any stride, stride-1 input gradients), with every epilogue variant
-// except the eval sibling GEMM's segments
-bool big_ok(const ConvArgs& a) { return !a.seg_n && !a.wKg && !(a.ish | a.isw); }
+bool big_ok(const ConvArgs& a) { return !a.wKg && !(a.ish | a.isw); }
 
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;

@@ -402,7 +402,11 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
     switch (o->kind) {
         case IFCBK_OP_CONV_FWD_AFFINE_SEG: {
             const ifcbk_conv_desc& d = o->u.conv;
-            snprintf(name, cap, "conv_igemm<unsigned short, %d, 2, 2, 4>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q));
+            int bmt = 0, btn = 0;
+            if (ifcbk_conv_big_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, &bmt, &btn))
+                snprintf(name, cap, "conv_pp2<%d, %d, %d, 4>", btn, bmt, bmt == 10 ? 4 : bmt / 2);
+            else
+                snprintf(name, cap, "conv_igemm<unsigned short, %d, 2, 2, 4>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q));
             break;
         }
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: {
