@@ -15,13 +15,13 @@ BF16, F32 = 0, 1
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
- OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD) = range(1, 31)
+ OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD, OP_CONV_DGRAD_BNSTAT_TAB) = range(1, 32)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
-            24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd'}
+            24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd', 31: 'conv_dgrad'}
 
 
 class ConvDesc(C.Structure):
@@ -49,6 +49,10 @@ class RoiDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('n_img', 'S', 'in_channels', 'out_channels', 'flip_bits_valid', 'dtype')] + \
                [('mean', C.c_float * 3), ('std', C.c_float * 3), ('tin_scale', C.c_float * 3),
                 ('tin_shift', C.c_float * 3)]
+
+
+class BsChunk(C.Structure):
+    _fields_ = [('raw', C.c_void_p), ('stat', C.c_void_p), ('raw_ld', C.c_int32), ('stat_ld', C.c_int32)]
 
 
 class PackItem(C.Structure):
@@ -96,6 +100,9 @@ _PROTOS = {
     'ifcbk_conv2d_dgrad_bnstat': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifcbk_bn_bwd_partials': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i,
                                    _vp]),
+    'ifcbk_bn_bwd_partials_ld': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
+                                      _i, _vp]),
+    'ifcbk_conv2d_dgrad_bnstat_table': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifcbk_bn_apply_maxpool': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'ifcbk_bn_bwd_maxpool': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i,
                                   _vp]),

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx,
 
 // pass 2: sum the row-tile partials (fixed order) -> dbeta, dgamma (+ temp copy used by pass 3)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int ntiles, int C, float* dgamma,
-                                                               float* dbeta, float* tmp, int accumulate) {
+                                                               float* dbeta, float* tmp, int accumulate, int ldp) {
     __shared__ double s[2][16][16];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + c;
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
             float v[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[2 * u] = part[((size_t)(i + 16 * u) * 2 + 0) * C + ch];
-                v[2 * u + 1] = part[((size_t)(i + 16 * u) * 2 + 1) * C + ch];
+                v[2 * u] = part[((size_t)(i + 16 * u) * 2 + 0) * ldp + ch];
+                v[2 * u + 1] = part[((size_t)(i + 16 * u) * 2 + 1) * ldp + ch];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
             }
         }
         for (; i < ntiles; i += 16) {
-            a += (double)part[((size_t)i * 2 + 0) * C + ch];
-            b += (double)part[((size_t)i * 2 + 1) * C + ch];
+            a += (double)part[((size_t)i * 2 + 0) * ldp + ch];
+            b += (double)part[((size_t)i * 2 + 1) * ldp + ch];
         }
     }
     s[0][rg][c] = a;
@@ -579,7 +579,7 @@ template <class T>
 int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy, int lddy,
           const float* gamma, const float* mean, const float* invstd, void* dx, int lddx, void* dres, int lddres,
           int dres_accumulate, float* dgamma, float* dbeta, int param_accumulate, const float* scale, const float* shift,
-          hipStream_t st, const PoolGather* pool = nullptr, const float* part_in = nullptr, int ntiles_in = 0) {
+          hipStream_t st, const PoolGather* pool = nullptr, const float* part_in = nullptr, int ntiles_in = 0, int part_ld_in = 0) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;
     PoolGather pg = {};
@@ -611,7 +611,7 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 2>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
         else hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 0>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce_pool2x2");
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate, C);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
         const float invM2 = (float)(1.0 / (double)M);
         const size_t shm2 = (size_t)5 * C * sizeof(float);
@@ -635,7 +635,7 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
     const int64_t total = M * (C / E);
     if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: tensor too large");
@@ -817,18 +817,26 @@ extern "C" int ifcbk_bn_apply_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, 
     return 0;
 }
 
+extern "C" int ifcbk_bn_bwd_partials_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* dy, int lddy,
+                                        const float* gamma, const float* mean, const float* invstd, const float* scale,
+                                        const float* shift, const float* part, int ntiles, int part_ld, void* dx, int lddx,
+                                        float* dgamma, float* dbeta, int param_accumulate, void* stream) {
+    if (!d || !part || ntiles <= 0 || part_ld < 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad args");
+    if (d->dtype == IFCBK_F32)
+        return bwd_t<float>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                            param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles, part_ld);
+    if (d->dtype == IFCBK_BF16)
+        return bwd_t<bf16_t>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
+                             param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles, part_ld);
+    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad dtype");
+}
+
 extern "C" int ifcbk_bn_bwd_partials(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* dy, int lddy,
                                      const float* gamma, const float* mean, const float* invstd, const float* scale,
                                      const float* shift, const float* part, int ntiles, void* dx, int lddx, float* dgamma,
                                      float* dbeta, int param_accumulate, void* stream) {
-    if (!d || !part || ntiles <= 0) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad args");
-    if (d->dtype == IFCBK_F32)
-        return bwd_t<float>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
-                            param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles);
-    if (d->dtype == IFCBK_BF16)
-        return bwd_t<bf16_t>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
-                             param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles);
-    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad dtype");
+    return ifcbk_bn_bwd_partials_ld(ctx, d, x, dy, lddy, gamma, mean, invstd, scale, shift, part, ntiles, 0, dx, lddx, dgamma, dbeta,
+                                    param_accumulate, stream);
 }
 
 extern "C" int ifcbk_bn_bwd_maxpool(ifcbk_ctx* ctx, const ifcbk_pool_desc* d, const void* x, const void* dpool,

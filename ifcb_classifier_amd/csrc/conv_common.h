@@ -20,6 +20,10 @@ struct ConvArgs {
     const void* bs_raw;
     const float *bs_mean, *bs_invstd, *bs_scale, *bs_shift;
     int bs_ld;
+    // ... or, when the output gradient belongs to a CONCATENATION of several producers (an Inception block output consumed by the
+    // next block's sibling GEMM): one entry per 8 output channels with that chunk's producer (raw tensor, statistics); raw == null:
+    // the chunk has no BatchNorm producer (a pooled slice).  Sums land in part[mblock][2][K] at the chunk's own columns.
+    const ifcbk_bs_chunk* bs_tab;
     unsigned xbytes, wbytes;   // buffer-descriptor extents of x and w
     int H, W, C, ldx;
     int K, R, S;
@@ -109,13 +113,31 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
         if (cvalid) {
             const int nn = n0 + cc * CE;
             float bmu[CE], bis[CE], bsc[CE], bsh[CE];
+            const T* braw = nullptr;                 // this thread's chunk of the producing BatchNorm's input, pixel 0
+            int bld = 0;
             if (BSTAT) {
+                if (a.bs_tab) {
+                    const ifcbk_bs_chunk e = a.bs_tab[nn >> 3];
+                    const int off = nn & 7;
+                    braw = e.raw ? (const T*)e.raw + off : nullptr;
+                    bld = e.raw_ld;
 #pragma unroll
-                for (int j = 0; j < CE; ++j) {
-                    bmu[j] = a.bs_mean[nn + j];
-                    bis[j] = a.bs_invstd[nn + j];
-                    bsc[j] = a.bs_scale[nn + j];
-                    bsh[j] = a.bs_shift[nn + j];
+                    for (int j = 0; j < CE; ++j) {
+                        bmu[j] = braw ? e.stat[off + j] : 0.f;
+                        bis[j] = braw ? e.stat[e.stat_ld + off + j] : 0.f;
+                        bsc[j] = braw ? e.stat[2 * e.stat_ld + off + j] : 0.f;
+                        bsh[j] = braw ? e.stat[3 * e.stat_ld + off + j] : 0.f;
+                    }
+                } else {
+                    braw = (const T*)a.bs_raw + nn;
+                    bld = a.bs_ld;
+#pragma unroll
+                    for (int j = 0; j < CE; ++j) {
+                        bmu[j] = a.bs_mean[nn + j];
+                        bis[j] = a.bs_invstd[nn + j];
+                        bsc[j] = a.bs_scale[nn + j];
+                        bsh[j] = a.bs_shift[nn + j];
+                    }
                 }
             }
             float sc[CE], sh[CE];
@@ -162,7 +184,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     if (m < a.M) {
                         if (a.accumulate) pre[u] = Chunk<T>::load_raw((const T*)a.y + opx[u] * a.ldy + nn);
                         if (a.ep_scale && a.ep_res) prer[u] = Chunk<T>::load_raw((const T*)a.ep_res + (size_t)m * a.ep_ldr + nn);
-                        if (BSTAT) prb[u] = Chunk<T>::load_raw((const T*)a.bs_raw + opx[u] * a.bs_ld + nn);
+                        if (BSTAT && braw) prb[u] = Chunk<T>::load_raw(braw + opx[u] * bld);
                     }
                 }
 #pragma unroll
@@ -176,7 +198,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     T* dst = MODE == 4 ? segbase + opx[u] * segld : (T*)a.y + opx[u] * a.ldy + nn;
                     float fv[CE];
                     if (a.part || a.accumulate || a.ep_scale) Chunk<T>::widen(rawc, fv);
-                    if (BSTAT) {
+                    if (BSTAT && braw) {
                         float fx[CE];
                         Chunk<T>::widen(prb[u], fx);
 #pragma unroll
@@ -188,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                             s1p[j / 2] += dz;
                             s2p[j / 2] += dz * xh;
                         }
-                    } else if (a.part) {
+                    } else if (!BSTAT && a.part) {
 #pragma unroll
                         for (int j = 0; j < CE; j += 2) {
                             const f32x2_t v = {fv[j], fv[j + 1]};

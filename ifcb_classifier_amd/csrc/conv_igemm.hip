@@ -686,7 +686,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     a.dbg = 0;
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
-    a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0;
+    a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0; a.bs_tab = nullptr;
     a.seg_n = seg ? seg->n : 0;
     for (int q = 0; q < 4; ++q) {
         a.seg_end[q] = seg ? seg->end[q] : 0; a.seg_ld[q] = seg ? seg->ld[q] : 0; a.seg_aff[q] = seg ? seg->aff[q] : 0;
@@ -710,6 +710,7 @@ struct BnStatArgs {
     int ld;
     const float *mean, *invstd, *scale, *shift;
     float* part;
+    const ifcbk_bs_chunk* tab;
 };
 
 // the fused variant exists for the plain (stride-1, first-writer, implicit-GEMM) input gradient only
@@ -742,7 +743,16 @@ extern "C" int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx* ctx, const ifcbk_conv_desc* 
     if (!d || !dgrad_bnstat_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_dgrad_bnstat: stride-1 implicit-GEMM input gradients only");
     if (!prev_raw || !prev_mean || !prev_invstd || !prev_scale || !prev_shift || !part)
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_dgrad_bnstat: null operand");
-    BnStatArgs bs = {prev_raw, prev_ld, prev_mean, prev_invstd, prev_scale, prev_shift, part};
+    BnStatArgs bs = {prev_raw, prev_ld, prev_mean, prev_invstd, prev_scale, prev_shift, part, nullptr};
+    return dgrad_impl(ctx, d, dy, wT, dx, 0, &bs, stream);
+}
+
+extern "C" int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
+                                               const ifcbk_bs_chunk* table, float* part, void* stream) {
+    if (!d || !dgrad_bnstat_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_dgrad_bnstat_table: stride-1 implicit-GEMM input gradients only");
+    if (!table || !part) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_dgrad_bnstat_table: null operand");
+    if (d->C % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_dgrad_bnstat_table: C must be a multiple of 8");
+    BnStatArgs bs = {table, 0, nullptr, nullptr, nullptr, nullptr, part, table};       // raw != null selects MODE 3
     return dgrad_impl(ctx, d, dy, wT, dx, 0, &bs, stream);
 }
 
@@ -759,7 +769,7 @@ static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, 
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
     a.x = dy; a.w = wT; a.y = dx; a.part = bs ? bs->part : nullptr;
     a.seg_n = 0;
-    a.bs_raw = bs ? bs->raw : nullptr; a.bs_ld = bs ? bs->ld : 0;
+    a.bs_raw = bs ? bs->raw : nullptr; a.bs_ld = bs ? bs->ld : 0; a.bs_tab = bs ? bs->tab : nullptr;
     a.bs_mean = bs ? bs->mean : nullptr; a.bs_invstd = bs ? bs->invstd : nullptr;
     a.bs_scale = bs ? bs->scale : nullptr; a.bs_shift = bs ? bs->shift : nullptr;
     const int es = dtype_esize(d->dtype);

@@ -133,9 +133,11 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_conv2d_dgrad_bnstat(c, &o->u.conv, p[0], p[1], p[2], p[3], (int)o->i[0], (const float*)p[4], (const float*)p[5],
                                              (const float*)p[6], (const float*)p[7], (float*)p[8], st);
         case IFCBK_OP_BN_BWD_PARTIALS:
-            return ifcbk_bn_bwd_partials(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                         (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], p[8], (int)o->i[2],
-                                         (float*)p[9], (float*)p[10], pacc, st);
+            return ifcbk_bn_bwd_partials_ld(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                            (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], (int)o->i[3], p[8],
+                                            (int)o->i[2], (float*)p[9], (float*)p[10], pacc, st);
+        case IFCBK_OP_CONV_DGRAD_BNSTAT_TAB:
+            return ifcbk_conv2d_dgrad_bnstat_table(c, &o->u.conv, p[0], p[1], p[2], (const ifcbk_bs_chunk*)p[3], (float*)p[4], st);
         case IFCBK_OP_CONV_FWD_AFFINE_SEG: {
             // i[s] = channels | pixel stride << 20 | affine << 40 of segment s (0 = unused); p[2..5] = destinations
             void* ys[4];
@@ -426,7 +428,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, 0>", ifcbk_conv_fwd_nt(d.K, d.N * d.P * d.Q), wm, wm == 4 ? 3 : 2);
             break;
         }
-        case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
+        case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_DGRAD_BNSTAT: case IFCBK_OP_CONV_DGRAD_BNSTAT_TAB: {
             const ifcbk_conv_desc& d = o->u.conv;
             int wm = ifcbk_conv_fwd_wm(d.N * d.H * d.W, d.C);
             {
@@ -437,7 +439,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 int bmt = 0, btn = 0;
                 if (!s2 && ifcbk_conv_big_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, &bmt, &btn)) {
-                    snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
+                    snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? 3 : 0);
                     break;
                 }
                 if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && !s2 && ifcbk_conv_ws_shape(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K)) {
@@ -446,7 +448,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 }
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
                 snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2,
-                         o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : classes ? 2 : (s2 ? 1 : 0));
+                         (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? 3 : classes ? 2 : (s2 ? 1 : 0));
             }
             break;
         }
@@ -484,13 +486,13 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
     double fl = 0, by = 0;
     switch (o->kind) {
         case IFCBK_OP_CONV_FWD: case IFCBK_OP_CONV_FWD_AFFINE: case IFCBK_OP_CONV_FWD_AFFINE_SEG: case IFCBK_OP_CONV_DGRAD: case IFCBK_OP_CONV_WGRAD:
-        case IFCBK_OP_CONV_WGRAD_SEG: case IFCBK_OP_CONV_DGRAD_BNSTAT: {
+        case IFCBK_OP_CONV_WGRAD_SEG: case IFCBK_OP_CONV_DGRAD_BNSTAT: case IFCBK_OP_CONV_DGRAD_BNSTAT_TAB: {
             const ifcbk_conv_desc& d = o->u.conv;
             double mac = (double)d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
             fl = 2.0 * mac;
             double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
                    wb = (double)d.K * d.R * d.S * d.C * 2;
-            by = xin + yout + wb + (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? xin : 0);      // + one read of the producer's raw output
+            by = xin + yout + wb + ((o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? xin : 0);      // + one read of the producer's raw output
             break;
         }
         case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;

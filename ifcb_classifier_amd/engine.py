@@ -476,6 +476,38 @@ class Engine:
         """a commuted pool branch's unpooled 1x1-conv output: its channel slice of the sibling GEMM's merged tensor"""
         return _vp(n.group.raw, self.esize * n.koff), n.group.Ktot
 
+    def _bs_table(self, grp, gd, readers, fused_pool):
+        """per-chunk producer table (ifcbk_bs_chunk) of the block input a sibling GEMM reads, when that GEMM is the input's only
+        consumer and every conv that wrote a slice of it is a plain conv -> BN -> ReLU; None otherwise"""
+        import numpy as np
+        x = grp.x
+        members = set(grp.members)
+        for r in readers.get(x.buf.id, ()):
+            if r not in members and not any(m.cpool is r for m in grp.members):
+                return None
+        prods = [m for m in self.net.nodes if m.kind != 'head' and m.y.buf.id == x.buf.id]
+        convs = [m for m in prods if m.kind == 'conv']
+        if not convs or not x.is_full:
+            return None
+        for m in convs:
+            if not m.relu or m.residual is not None or m in fused_pool or m.aux:
+                return None
+        nrow = self.ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(gd))
+        if nrow <= 0:
+            return None
+        nchunk = x.C // 8
+        tab = (_lib.BsChunk * nchunk)()
+        for m in convs:
+            rawp, rawld = self._raw_ptr(m)
+            for k in range(m.K // 8):
+                e = tab[m.y.coff // 8 + k]
+                e.raw = rawp.value + k * 8 * self.esize
+                e.stat = self.stats.data_ptr() + 4 * (m.st_off + k * 8)
+                e.raw_ld, e.stat_ld = rawld, m.st_ld
+        table = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(self.dev)
+        part = torch.zeros(nrow * 2 * x.C, dtype=torch.float32, device=self.dev)
+        return table, part, nrow, convs
+
     # ------------------------------------------------------------------ programs
     def plan(self, N):
         if N > self.max_batch:
@@ -516,7 +548,9 @@ class Engine:
         # conv c whose input is the private BN+ReLU activation of conv n: c's input-gradient kernel also reduces n's BN
         # backward sums in its epilogue (ifcbk_conv2d_dgrad_bnstat) and n's BN backward skips its reduction pass
         bnstat_of = {}        # consumer conv -> producer conv
-        if os.environ.get('IFCBK_FUSE_BNSTAT', '1') != '0':
+        fuse_bnstat = os.environ.get('IFCBK_FUSE_BNSTAT', '1') != '0'
+        keep = []             # device tables / buffers the op tables point into
+        if fuse_bnstat:
             for cnode in net.nodes:
                 if cnode.kind != 'conv' or cnode.group is not None or cnode.x.buf.is_input or not cnode.x.is_full:
                     continue
@@ -805,13 +839,13 @@ class Engine:
                                self._pptr(bkey + '.weight', 'G'), self._pptr(bkey + '.bias', 'G')),
                             i=(1, n.K), pool=ppd, lane=L, reads=[rraw(n), rg(pn.y), ram(pk), rst(n)], writes=rdraw)
                 elif n in bnstat_done:
-                    ppart, nrow, pl_ = bnstat_done[n]
+                    ppart, nrow, pres, pld = bnstat_done[n]
                     bwd.add(_lib.OP_BN_BWD_PARTIALS, n.name,
                             p=(rawp, self._aptr(n.y, True), self._pptr(bkey + '.weight'), self._stat(n, 0), self._stat(n, 1),
                                self._stat(n, 2), self._stat(n, 3), ppart, draw, self._pptr(bkey + '.weight', 'G'),
                                self._pptr(bkey + '.bias', 'G')),
-                            i=(n.y.buf.C, nrow, n.K if grp is None else grp.Ktot), bn=bnd, lane=L,
-                            reads=[rraw(n), rg(n.y), rst(n), rbp(pl_)], writes=rdraw)
+                            i=(n.y.buf.C, nrow, n.K if (grp is None or cp) else grp.Ktot, pld), bn=bnd, lane=L,
+                            reads=[rraw(n), rg(n.y), rst(n), pres], writes=rdraw)
                 else:
                     bwd.add(_lib.OP_BN_BWD, n.name,
                             p=(rawp, self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
@@ -839,9 +873,24 @@ class Engine:
                                 p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd,
                                 lane=0, reads=[ra(grp.x), gres], writes=[])
                         acc = acc_flag(grp.x.buf)
-                        bwd.add(_lib.OP_CONV_DGRAD, '+'.join(m.name for m in grp.members),
-                                p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
-                                flags=acc, conv=gd, lane=0, reads=[gres], writes=[rg(grp.x)])
+                        tab = self._bs_table(grp, gd, readers, fused_pool) if (acc == 0 and fuse_bnstat) else None
+                        if tab is not None:
+                            # the sibling GEMM is the ONLY consumer of this block input: its input-gradient kernel is the sole writer
+                            # of the block-output gradient and reduces the BatchNorm-backward sums of every producer of that
+                            # concatenation in its epilogue (per-chunk producer table); the producers skip their reduction pass
+                            table, part, nrow, prods = tab
+                            keep.extend([table, part])
+                            rpt = ('bpt', id(grp), 0, 1)
+                            bwd.add(_lib.OP_CONV_DGRAD_BNSTAT_TAB, '+'.join(m.name for m in grp.members),
+                                    p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True), _vp(table),
+                                       _vp(part)), conv=gd, lane=0,
+                                    reads=[gres] + [rraw(m) for m in prods] + [rst(m) for m in prods], writes=[rg(grp.x), rpt])
+                            for m in prods:
+                                bnstat_done[m] = (_vp(part, 4 * m.y.coff), nrow, rpt, grp.x.C)
+                        else:
+                            bwd.add(_lib.OP_CONV_DGRAD, '+'.join(m.name for m in grp.members),
+                                    p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
+                                    flags=acc, conv=gd, lane=0, reads=[gres], writes=[rg(grp.x)])
                     continue
                 dbw = ConvDesc.from_buffer_copy(d)
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
@@ -861,7 +910,7 @@ class Engine:
                                 p=(draw, wT, self._aptr(n.x, True), prow, self._stat(pn, 0), self._stat(pn, 1),
                                    self._stat(pn, 2), self._stat(pn, 3), _vp(self.bn_part[L])), i=(pld,), conv=dbw,
                                 lane=L, reads=rdraw + [rraw(pn), rst(pn)], writes=[rg(n.x), rbp(L)])
-                        bnstat_done[pn] = (_vp(self.bn_part[L]), nrow, L)
+                        bnstat_done[pn] = (_vp(self.bn_part[L]), nrow, rbp(L), 0)
                     else:
                         bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(draw, wT, self._aptr(n.x, True)), flags=acc, conv=dbw,
                                 lane=L, reads=rdraw, writes=[rg(n.x)])
@@ -920,6 +969,7 @@ class Engine:
         pl.adam_pack = Program(ap)
         pl.bwd_list = bwd
         pl.ddp_segs = None
+        pl.keep = keep
         return pl
 
     def _pack_multi(self, pack):

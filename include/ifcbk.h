@@ -255,6 +255,21 @@ int ifcbk_bn_bwd_maxpool(ifcbk_ctx*, const ifcbk_pool_desc* d, const void* x, co
  * ifcbk_conv2d_dgrad + ifcbk_bn_bwd up to the summation order of the two per-channel sums.
  * Replaces autograd of [TV] BasicConv2d chains (inception.py), reference call site neuston_models.py:66-68,81-86.  */
 int ifcbk_conv2d_dgrad_bnstat_mblocks(const ifcbk_conv_desc*);
+/* The same fusion when dx is the gradient of a CONCATENATION of several BatchNorm+ReLU outputs (an Inception block output whose only
+ * consumer is the next block's sibling 1x1 GEMM): `table` (device memory) holds one entry per 8 channels of dx naming that chunk's
+ * producer -- `raw`: the producing BatchNorm's input at this chunk's first channel, pixel 0 (pixel stride raw_ld elements); `stat`:
+ * that channel's mean, with invstd / scale / shift at +stat_ld, +2 stat_ld, +3 stat_ld floats; raw == NULL: no BatchNorm producer
+ * (a pooled slice), its sums are zero.  part [mblocks][2][C]: every producer reads its own column range with row stride C
+ * (ifcbk_bn_bwd_partials_ld).  Replaces autograd through [TV] torch.cat(...) of InceptionA/B/C/D/E.forward (reference call site
+ * neuston_models.py:66-68,81-86).                                                                                              */
+typedef struct {
+    const void*  raw;
+    const float* stat;
+    int32_t      raw_ld;
+    int32_t      stat_ld;
+} ifcbk_bs_chunk;
+int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
+                                    const ifcbk_bs_chunk* table, float* part, void* stream);
 int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
                               const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
                               const float* prev_scale, const float* prev_shift, float* part, void* stream);
@@ -263,6 +278,11 @@ int ifcbk_bn_bwd_partials(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const
                           const float* gamma, const float* mean, const float* invstd, const float* scale,
                           const float* shift, const float* part, int ntiles, void* dx, int lddx, float* dgamma,
                           float* dbeta, int param_accumulate, void* stream);
+/* ... with an explicit row stride of `part` (floats; 0 = C): this layer's columns inside a wider partial-sum matrix            */
+int ifcbk_bn_bwd_partials_ld(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* dy, int lddy,
+                             const float* gamma, const float* mean, const float* invstd, const float* scale,
+                             const float* shift, const float* part, int ntiles, int part_ld, void* dx, int lddx,
+                             float* dgamma, float* dbeta, int param_accumulate, void* stream);
 
 /* ------------------------------------------------------------------ program runner
  * One call launches a whole forward / backward / update list: the host builds the op table once
@@ -276,7 +296,8 @@ enum {
     IFCBK_OP_WEIGHT_PACK_MULTI, IFCBK_OP_CONV_WGRAD_SEG, IFCBK_OP_BN_APPLY_MAXPOOL, IFCBK_OP_BN_BWD_MAXPOOL,
     IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE,
     IFCBK_OP_CONV_FWD_AFFINE_SEG,
-    IFCBK_OP_SGD             /* p: P, G, momentum buffer (nullable); i[0] = n; f: lr, momentum, weight decay, grad scale */
+    IFCBK_OP_SGD,            /* p: P, G, momentum buffer (nullable); i[0] = n; f: lr, momentum, weight decay, grad scale */
+    IFCBK_OP_CONV_DGRAD_BNSTAT_TAB   /* p: dy, wT, dx, table, part (ifcbk_conv2d_dgrad_bnstat_table)                           */
 };
 typedef struct {
     int32_t kind;
