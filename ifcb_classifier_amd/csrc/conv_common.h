@@ -165,7 +165,10 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
             // whole batch are requested before the first is used -- one exposed memory latency per batch instead of per row
             // (an accumulating 1x1 dgrad into a 288-channel block input ran at 1.5 TB/s with a load -> wait -> store loop)
             constexpr int RT = BM / RPP;
-            constexpr int UB = BSTAT ? 4 : (RT < 8 ? RT : 8);
+            // BSTAT: the producer's raw chunks of ALL rows of this thread are requested up front (the accumulators are dead by now,
+            // registers are plentiful): with batches of 4 a 256 x 256 tile paid five exposed HBM latencies per thread and the fused
+            // kernel took twice the plain one's time
+            constexpr int UB = BSTAT ? (RT % 8 == 0 ? 8 : 4) : (RT < 8 ? RT : 8);
             for (int b = 0; b < RT; b += UB) {
                 typename Chunk<T>::raw_t pre[UB], prer[UB], prb[UB];
                 size_t opx[UB];

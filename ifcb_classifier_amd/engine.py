@@ -548,7 +548,10 @@ class Engine:
         # conv c whose input is the private BN+ReLU activation of conv n: c's input-gradient kernel also reduces n's BN
         # backward sums in its epilogue (ifcbk_conv2d_dgrad_bnstat) and n's BN backward skips its reduction pass
         bnstat_of = {}        # consumer conv -> producer conv
-        fuse_bnstat = os.environ.get('IFCBK_FUSE_BNSTAT', '1') != '0'
+        # 0 off, 1 one-producer layers, 2 + block outputs through a chunk table.  Level 2 is correct (tests run it) but measured
+        # SLOWER at batch 256 (the wide-tile dgrads run one block per CU, nothing hides their epilogue): default 1
+        fuse_level = int(os.environ.get('IFCBK_FUSE_BNSTAT', '1'))
+        fuse_bnstat = fuse_level >= 1
         keep = []             # device tables / buffers the op tables point into
         if fuse_bnstat:
             for cnode in net.nodes:
@@ -873,7 +876,7 @@ class Engine:
                                 p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd,
                                 lane=0, reads=[ra(grp.x), gres], writes=[])
                         acc = acc_flag(grp.x.buf)
-                        tab = self._bs_table(grp, gd, readers, fused_pool) if (acc == 0 and fuse_bnstat) else None
+                        tab = self._bs_table(grp, gd, readers, fused_pool) if (acc == 0 and fuse_level >= 2) else None
                         if tab is not None:
                             # the sibling GEMM is the ONLY consumer of this block input: its input-gradient kernel is the sole writer
                             # of the block-output gradient and reduces the BatchNorm-backward sums of every producer of that

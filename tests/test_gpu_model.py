@@ -31,10 +31,22 @@ def _loss(out, y):
     return F.cross_entropy(out, y)
 
 
-@pytest.mark.parametrize('name,nc,B,S', [('inception_v3', 10, 4, 299), ('resnet18', 2, 6, 224), ('resnet50', 3, 4, 224),
-                                         ('resnet34', 5, 3, 224)])
-def test_train_step_local_parity(name, nc, B, S):
+# last column: IFCBK_FUSE_BNSTAT -- BatchNorm-backward sums in dgrad epilogues off (0) / also through the chunk table of block
+# outputs (2); None = the default (1, layers with one producer and one consumer)
+@pytest.mark.parametrize('name,nc,B,S,fuse', [('inception_v3', 10, 4, 299, None), ('resnet18', 2, 6, 224, None),
+                                              ('resnet50', 3, 4, 224, None), ('resnet34', 5, 3, 224, None),
+                                              ('inception_v3', 10, 4, 299, '0'), ('inception_v3', 10, 4, 299, '2')])
+def test_train_step_local_parity(name, nc, B, S, fuse, monkeypatch):
+    if fuse is not None:
+        monkeypatch.setenv('IFCBK_FUSE_BNSTAT', fuse)
     hip, ora = _pair(name, nc, B)
+    if fuse is not None:
+        from ifcb_classifier_amd import _lib
+        prog = hip.engine.plan(B).step
+        kinds = [prog.arr[k].kind for k in range(prog.n)]
+        one, tab = kinds.count(_lib.OP_CONV_DGRAD_BNSTAT), kinds.count(_lib.OP_CONV_DGRAD_BNSTAT_TAB)
+        print('IFCBK_FUSE_BNSTAT', fuse, 'one-producer fusions', one, 'table fusions', tab)
+        assert (one, tab) == (0, 0) if fuse == '0' else (one > 0 and tab > 0)
     x = torch.rand(B, 3, S, S)
     y = torch.randint(0, nc, (B,))
     mask = None
