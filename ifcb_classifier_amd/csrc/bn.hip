@@ -541,9 +541,15 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const T* x, int ldx, con
             fd[j] = dz;
             o[j] = coef[c + j] * dz + (coef[C + c + j] * fx[j] + coef[2 * C + c + j]);
         }
+        if (dres_acc & 2) {                      // dx accumulates (densenet: a concatenation's gradient collects every later layer's share)
+            float fo[E];
+            Chunk<T>::load(dx + (int64_t)m * lddx + c, fo);
+#pragma unroll
+            for (int j = 0; j < E; ++j) o[j] += fo[j];
+        }
         if (dres) {
             T* rp = dres + (int64_t)m * lddres + c;
-            if (dres_acc) {
+            if (dres_acc & 1) {
                 float fr[E];
                 Chunk<T>::load(rp, fr);
 #pragma unroll

@@ -481,14 +481,16 @@ int pick_nt(int K, int maxnt, int M, int bm) {
     return best;
 }
 
-int check_desc(ifcbk_ctx* ctx, const ifcbk_conv_desc* d) {
+// (the forward gather takes any stride -- alexnet's first conv is 11x11 / stride 4; the input gradient's dilated gather and its
+// parity-class split are written for strides 1 and 2)
+int check_desc(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, bool dgrad = false) {
     if (!d) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: null desc");
     if (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv: dtype must be bf16 or f32");
     const int ce = dtype_chunk(d->dtype), es = dtype_esize(d->dtype);
     if (d->C % ce || d->K % ce || d->ldx % ce || d->ldy % ce || d->C <= 0 || d->K <= 0)
         IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: C=%d K=%d ldx=%d ldy=%d must be positive multiples of %d", d->C, d->K, d->ldx, d->ldy, ce);
-    if (d->stride_h < 1 || d->stride_h > 2 || d->stride_w < 1 || d->stride_w > 2)
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: stride must be 1 or 2");
+    if (d->stride_h < 1 || d->stride_w < 1 || (dgrad && (d->stride_h > 2 || d->stride_w > 2)))
+        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: stride must be >= 1 (1 or 2 for the input gradient)");
     int P = (d->H + 2 * d->pad_h - d->R) / d->stride_h + 1, Q = (d->W + 2 * d->pad_w - d->S) / d->stride_w + 1;
     if (P != d->P || Q != d->Q) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv: P,Q=%d,%d inconsistent (expect %d,%d)", d->P, d->Q, P, Q);
     if ((int64_t)d->N * d->P * d->Q * d->ldy * es >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * es >= (1ll << 31))
@@ -758,7 +760,7 @@ extern "C" int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx* ctx, const ifcbk_conv_
 
 static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx, int accumulate,
                       const BnStatArgs* bs, void* stream) {
-    if (int e = check_desc(ctx, d)) return e;
+    if (int e = check_desc(ctx, d, true)) return e;
     // the input gradient of a 3x3/stride-1 conv is a 3x3/stride-1 conv of dy with the flipped filter (wT), padding 2 - pad
     if (!bs && !accumulate && ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W))
         return ifcbk_conv_rows_launch(ctx, d->K, d->C, d->N, d->P, d->Q, d->ldy, d->H, d->W, d->ldx, 2 - d->pad_h, 2 - d->pad_w, dy,

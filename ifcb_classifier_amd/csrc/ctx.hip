@@ -127,7 +127,7 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             return ifcbk_bn_apply(c, &o->u.bn, p[0], (const float*)p[1], (const float*)p[2], p[3], (int)o->i[0], p[4], st);
         case IFCBK_OP_BN_BWD:
             return ifcbk_bn_bwd(c, &o->u.bn, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
-                                (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc, (float*)p[8], (float*)p[9],
+                                (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc | (((o->flags >> 3) & 1) << 1), (float*)p[8], (float*)p[9],
                                 pacc, (const float*)p[10], (const float*)p[11], st);
         case IFCBK_OP_CONV_DGRAD_BNSTAT:
             return ifcbk_conv2d_dgrad_bnstat(c, &o->u.conv, p[0], p[1], p[2], p[3], (int)o->i[0], (const float*)p[4], (const float*)p[5],
@@ -184,6 +184,14 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
             IFCBK_HIP(c, hipMemcpy2DAsync(p[0], (size_t)o->i[0], p[1], (size_t)o->i[1], (size_t)o->i[2], (size_t)o->i[3],
                                           hipMemcpyDeviceToDevice, (hipStream_t)st));
             return 0;
+        case IFCBK_OP_BIAS_RELU_BWD:
+            return ifcbk_bias_relu_bwd(c, o->u.bn.M, o->u.bn.C, o->u.bn.dtype, p[0], o->u.bn.ldx, p[1], o->u.bn.ldy, p[2], (int)o->i[0],
+                                       o->u.bn.relu, (float*)p[3], pacc, st);
+        case IFCBK_OP_DROPOUT:
+            return ifcbk_dropout_apply(c, o->i[0], (int)o->i[1], p[0], (const uint8_t*)p[1], o->f[0], p[2], acc, st);
+        case IFCBK_OP_FLATTEN_CHW:
+            return ifcbk_flatten_chw(c, (int)o->i[0], (int)o->i[1], (int)o->i[2], (int)(o->i[3] >> 32), p[0], (int)(o->i[3] & 0xffffffff),
+                                     p[1], (o->flags >> 2) & 1, acc, st);
         case IFCBK_OP_DROPOUT_MASK:
             return ifcbk_dropout_mask(c, (uint8_t*)p[0], o->i[0], o->f[0], (uint64_t)o->i[1], (uint64_t)o->i[2], st);
         default: IFCBK_FAIL(c, IFCBK_EINVAL, "run_program: unknown op kind %d", o->kind);
@@ -475,6 +483,9 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_AVGPOOL_BWD: snprintf(name, cap, "avgpool_bwd_kernel"); break;
         case IFCBK_OP_ADAM: snprintf(name, cap, "adam_kernel"); break;
         case IFCBK_OP_SGD: snprintf(name, cap, "sgd_kernel"); break;
+        case IFCBK_OP_BIAS_RELU_BWD: snprintf(name, cap, "bias_relu_bwd_kernel"); break;
+        case IFCBK_OP_DROPOUT: snprintf(name, cap, "dropout_apply_kernel"); break;
+        case IFCBK_OP_FLATTEN_CHW: snprintf(name, cap, "flatten_chw_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK: snprintf(name, cap, "weight_pack_kernel"); break;
         case IFCBK_OP_WEIGHT_PACK_MULTI: snprintf(name, cap, "weight_pack_multi_kernel"); break;
         default: break;

@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void gap_kernel(const T* x, int ldx, int HW, i
 // logits[n][j] = feat[n] . W[j] + b[j].  Block = FC_NB samples x one quarter of the classes: the FC_NB feature rows
 // sit in LDS, each wave owns a class and streams its weight row ONCE for all FC_NB samples (fixed summation order:
 // lane-strided partial sums, then a butterfly -- independent of the grid).
-constexpr int FC_NB = 8;
+// (FC_NB = 8 samples per block up to 2048 features, 4 up to 4096 -- the alexnet / vgg classifier -- for the 64 KiB of LDS)
+template <int FC_NB>
 __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* feat, const float* W, const float* b, float* logits,
                                                      int N, int C, int NC) {
     extern __shared__ float sf[];                 // [FC_NB][C]
@@ -519,12 +520,17 @@ __global__ __launch_bounds__(256) void head_dx_kernel(const float* dl, const flo
     float g[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) g[j] = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < NC; ++k) {
-        float d = dl[n * NC + k];
-        const float* w = W + (size_t)k * C + c;
+    if (!W) {                                       // pooled-logits form: d(pooled channel c) = dl[n][c] for c < NC
 #pragma unroll
-        for (int j = 0; j < E; ++j) g[j] += d * w[j];
+        for (int j = 0; j < E; ++j) g[j] = c + j < NC ? dl[n * NC + c + j] : 0.f;
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < NC; ++k) {
+            float d = dl[n * NC + k];
+            const float* w = W + (size_t)k * C + c;
+#pragma unroll
+            for (int j = 0; j < E; ++j) g[j] += d * w[j];
+        }
     }
     const float inv = 1.f / (float)HW;
 #pragma unroll
@@ -760,12 +766,21 @@ extern "C" int ifcbk_head_fwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const vo
     if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: bad desc");
     const int e = dtype_chunk(d->dtype);
     if (d->C % e || d->ldx % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: channels must be multiples of %d", e);
-    if ((size_t)d->C * 4 * 8 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
+    if (W && (size_t)d->C * 4 * 4 > 64 * 1024) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: C too large");
+    if (!W && d->NC > d->C) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_fwd: the pooled-logits form needs NC <= C");
     int64_t total = (int64_t)d->N * (d->C / e);
     if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(gap_kernel<float>, dim3(cdiv(total * GAP_SPLIT, 256)), dim3(256), 0, ST, (const float*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
     else hipLaunchKernelGGL(gap_kernel<bf16_t>, dim3(cdiv(total * GAP_SPLIT, 256)), dim3(256), 0, ST, (const bf16_t*)x, d->ldx, d->HW, d->C, total, mask, d->keep_scale, feat);
     IFCBK_LAUNCH_CHECK(ctx, "gap");
-    hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv(d->N, FC_NB), cdiv(d->NC, 8)), dim3(256), (size_t)FC_NB * d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->N, d->C, d->NC);
+    if (!W) {
+        // squeezenet's classifier ends in the pool itself (Dropout -> Conv2d(512, NC, 1) -> ReLU -> AdaptiveAvgPool2d(1)): the
+        // logits are the first NC pooled channels (the conv's output channels are padded to a whole 16-byte chunk)
+        IFCBK_HIP(ctx, hipMemcpy2DAsync(logits, (size_t)d->NC * 4, feat, (size_t)d->C * 4, (size_t)d->NC * 4, (size_t)d->N,
+                                        hipMemcpyDeviceToDevice, ST));
+        return 0;
+    }
+    if (d->C <= 2048) hipLaunchKernelGGL(fc_fwd_kernel<8>, dim3(cdiv(d->N, 8), cdiv(d->NC, 8)), dim3(256), (size_t)8 * d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->N, d->C, d->NC);
+    else hipLaunchKernelGGL(fc_fwd_kernel<4>, dim3(cdiv(d->N, 4), cdiv(d->NC, 8)), dim3(256), (size_t)4 * d->C * sizeof(float), ST, (const float*)feat, W, b, logits, d->N, d->C, d->NC);
     IFCBK_LAUNCH_CHECK(ctx, "fc_fwd");
     return 0;
 }
@@ -775,10 +790,12 @@ extern "C" int ifcbk_head_bwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const fl
     if (!d || (d->dtype != IFCBK_BF16 && d->dtype != IFCBK_F32)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: bad desc");
     const int e = dtype_chunk(d->dtype);
     if (d->C % e || lddx % e) IFCBK_FAIL(ctx, IFCBK_EINVAL, "head_bwd: channels must be multiples of %d", e);
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((int64_t)d->NC * d->C, 256)), dim3(256), 0, ST, dlogits, feat, dW, d->N, d->C, d->NC, param_accumulate);
-    IFCBK_LAUNCH_CHECK(ctx, "fc_wgrad");
-    hipLaunchKernelGGL(fc_bgrad_kernel, dim3(cdiv(d->NC, 64)), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
-    IFCBK_LAUNCH_CHECK(ctx, "fc_bgrad");
+    if (W) {
+        hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((int64_t)d->NC * d->C, 256)), dim3(256), 0, ST, dlogits, feat, dW, d->N, d->C, d->NC, param_accumulate);
+        IFCBK_LAUNCH_CHECK(ctx, "fc_wgrad");
+        hipLaunchKernelGGL(fc_bgrad_kernel, dim3(cdiv(d->NC, 64)), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
+        IFCBK_LAUNCH_CHECK(ctx, "fc_bgrad");
+    }
     if (dx) {
         int64_t total = (int64_t)d->N * (d->C / e);
         if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(head_dx_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, ST, dlogits, W, mask, d->keep_scale, (float*)dx, lddx, d->HW, d->C, d->NC, total);

@@ -193,11 +193,19 @@ class Engine:
         net, dev = self.net, self.dev
         off = 0
         self.poff = {}
+        self.palloc = {}          # flat offset -> padded element count of the tensor stored there
         for key, shape, kind, node in net.params:
-            n = int(math.prod(shape))
+            n = na = int(math.prod(shape))
+            if getattr(node, 'kind', '') == 'cb' and node.K != node.K_real:
+                na = n // shape[0] * node.K       # output channels padded to a whole 16-byte chunk: the extra rows stay zero
             self.poff[key] = (off, n, shape, kind, node)
-            off += (n + 3) // 4 * 4           # keep every tensor 16-byte aligned
+            self.palloc[off] = (na + 3) // 4 * 4
+            off += (na + 3) // 4 * 4          # keep every tensor 16-byte aligned
         self.nparam_padded = off
+        self.cbias_after = {}
+        for key, (o, n, shape, kind, node) in self.poff.items():
+            if kind == 'bn_cbias':
+                self.cbias_after[self.poff[node.bn_key + '.weight'][0]] = [o]
         self.P = torch.zeros(off, dtype=torch.float32, device=dev)
         self.G = torch.zeros(off, dtype=torch.float32, device=dev)
         self.M = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -224,7 +232,12 @@ class Engine:
                 v.fill_(1.0)
         convs = [n for n in net.nodes if getattr(n, 'kind', '') == 'conv']
         self.convs = convs
-        self.nbt = torch.zeros(len(convs), dtype=torch.int64, device=dev)        # num_batches_tracked (all BNs)
+        self.plains = [n for n in net.nodes if n.kind == 'cb']       # conv (+bias) (+ReLU) without BatchNorm, nn.Linear layers
+        self.bnrs = [n for n in net.nodes if n.kind == 'bnr']        # BatchNorm -> ReLU in front of a conv (densenet)
+        self.bn_nodes = [n for n in net.nodes if n.kind in ('conv', 'bnr')]
+        self.bn_index = {n: k for k, n in enumerate(self.bn_nodes)}
+        self.nbt = torch.zeros(len(self.bn_nodes), dtype=torch.int64, device=dev)        # num_batches_tracked (all BNs)
+        self.ones = torch.ones(max([n.K for n in self.plains] + [8]), dtype=torch.float32, device=dev)
         # bf16 shadows + per-BN statistics
         # horizontal fusion: sibling 1x1 convs that read the same tensor become ONE GEMM (filters concatenated along K)
         # in the training forward / dgrad / wgrad; their BatchNorms stay per branch on channel slices.
@@ -310,6 +323,17 @@ class Engine:
                     m.wT_off = g.wT_off + m.koff
                     m.wT_ld = g.Ktot
                     m.st_off, m.st_ld = g.st_off + m.koff, g.Ktot
+        for n in self.plains:
+            n.group = None
+            n.w_off = soff
+            soff += n.K * n.R * n.S * n.x.C
+            n.wT_off = soff
+            soff += n.K * n.R * n.S * n.x.C
+            n.wT_ld = 0
+        for n in self.bnrs:
+            n.group = None
+            n.st_off, n.st_ld = stoff, n.K
+            stoff += 6 * n.K
         self.Wsh = torch.zeros(soff, dtype=self.tdtype, device=dev)
         self.stats = torch.zeros(stoff, dtype=torch.float32, device=dev)
 
@@ -323,7 +347,37 @@ class Engine:
         incep = self.net.name == 'inception_v3'
         for key, (o, n, shape, kind, node) in self.poff.items():
             v = self.pviews[key]
-            if kind == 'conv':
+            how = getattr(node, 'init', None)
+            if kind in ('conv', 'lin_w') and how is not None:
+                # [TV] alexnet: torch defaults; vgg: kaiming_normal(fan_out) convs, N(0, 0.01) Linears, zero biases; squeezenet:
+                # kaiming_uniform convs, zero biases; densenet: kaiming_normal (fan_in) convs; the layers the reference replaces
+                # (neuston_models.py:27-42) keep torch's default init
+                rf = shape[2] * shape[3] if len(shape) == 4 else 1
+                fan_in, fan_out = shape[1] * rf, shape[0] * rf
+                w = torch.empty(shape)
+                if how == 'default':
+                    w.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in), generator=g)
+                elif how == 'kaiming_uniform':
+                    w.uniform_(-math.sqrt(6.0 / fan_in), math.sqrt(6.0 / fan_in), generator=g)
+                elif how == 'kaiming_out':
+                    w.normal_(0, math.sqrt(2.0 / fan_out), generator=g)
+                elif how == 'kaiming_in':
+                    w.normal_(0, math.sqrt(2.0 / fan_in), generator=g)
+                elif how == 'normal01':
+                    w.normal_(0, 0.01, generator=g)
+                else:
+                    raise ValueError(how)
+                v.copy_(w.to(self.dev))
+            elif kind == 'cbias':
+                wshape = self.poff[key[:-4] + 'weight'][2]
+                fan_in = int(math.prod(wshape[1:]))
+                if node.init == 'default':
+                    v.copy_(((torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)).to(self.dev))
+                else:
+                    v.zero_()
+            elif kind == 'bn_cbias':
+                v.zero_()
+            elif kind == 'conv':
                 w = torch.empty(shape)
                 if incep:
                     std = 0.01 if key.startswith('AuxLogits.conv1') else 0.1
@@ -372,7 +426,7 @@ class Engine:
                 need_grad.add(n.y.buf.id)
                 if n.residual is not None:
                     need_grad.add(n.residual.buf.id)
-            elif n.kind in ('max', 'avg'):
+            elif n.kind in ('max', 'avg', 'cb', 'drop', 'flat', 'bnr'):
                 need_grad.add(n.y.buf.id)
         need_grad.discard(net.input.id)
         for bid in need_grad:
@@ -400,14 +454,15 @@ class Engine:
         self.graph_train = gm in ('1', 'all', 'train')
         self.wgrad_side_lane = os.environ.get('IFCBK_WGRAD_SIDE', '0') != '0' and self.NL > 1
         self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
-        max_raw = max(n.P * n.Q * n.K for n in self.convs)
+        max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
         # the next node's BN backward already fills the other)
         self.draw = [torch.zeros(N * max_raw, dtype=bf, device=dev) for _ in range(self.NL * (2 if self.wgrad_side_lane else 1))]
         gmax = max([g.x.H * g.x.W * g.Ktot for g in self.groups] + [0])
         self.draw_group = torch.zeros(max(1, N * gmax), dtype=bf, device=dev)
         mb = max([self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs] +
-                 [self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._group_desc(g, N))) * 2 * g.Ktot for g in self.groups])
+                 [self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._group_desc(g, N))) * 2 * g.Ktot for g in self.groups] +
+                 [self.ctx.lib.ifcbk_bn_stats_rows(N * n.x.H * n.x.W) * 2 * n.K for n in self.bnrs] + [16])
         self.bn_part = [torch.zeros(mb, dtype=torch.float32, device=dev) for _ in range(self.NL)]
         self.argmax = {}
         for k, n in enumerate(net.nodes):
@@ -419,6 +474,9 @@ class Engine:
             h.logits = torch.zeros(N, h.NC, dtype=torch.float32, device=dev)
             h.dlogits = torch.zeros(N, h.NC, dtype=torch.float32, device=dev)
             h.mask = torch.ones(N, h.C, dtype=torch.uint8, device=dev) if h.dropout else None
+        self.drops = [n for n in net.nodes if n.kind == 'drop']
+        for n in self.drops:
+            n.mask = torch.ones(N, n.x.H * n.x.W * n.x.C, dtype=torch.uint8, device=dev)
         self.probs = torch.zeros(N, net.NC, dtype=torch.float32, device=dev)
         self.target = torch.zeros(N, dtype=torch.int64, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -432,6 +490,12 @@ class Engine:
             ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         for g in self.groups:
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, N))))
+        for n in self.plains:
+            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._conv_desc(n, N))),
+                     self.ctx.lib.ifcbk_bias_relu_bwd_workspace(N * n.P * n.Q, n.K))
+        for n in self.bnrs:
+            M = N * n.x.H * n.x.W
+            ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         self.ctx.reserve(ws)
 
     def activation_bytes(self):
@@ -450,6 +514,21 @@ class Engine:
             return ConvDesc(N, 1, 1, CC, CC, n.K, 1, 1, 1, 1, 0, 0, 1, 1, n.y.buf.C, CC, self.cdtype)
         return ConvDesc(N, n.x.H, n.x.W, n.x.C, n.x.buf.C, n.K, n.R, n.S, n.sh, n.sw, n.ph, n.pw, n.P, n.Q,
                         n.y.buf.C, n.Cw, self.cdtype)
+
+    def zeros_k(self, K):
+        z = getattr(self, '_zeros_k', None)
+        if z is None or z.numel() < K:
+            z = self._zeros_k = torch.zeros(max(K, 4096), dtype=torch.float32, device=self.dev)
+        return z
+
+    def _pack_desc(self, n, d):
+        """weight_pack of a layer whose output channels were padded (squeezenet's classifier conv): only the true rows exist in
+        the fp32 master; the shadow rows behind them stay zero"""
+        if n.K_real == n.K:
+            return d
+        dp = ConvDesc.from_buffer_copy(d)
+        dp.K = n.K_real
+        return dp
 
     def _group_desc(self, g, N):
         x = g.x
@@ -790,9 +869,64 @@ class Engine:
                     if n.aux and not train:
                         continue
                     mask = _vp(n.mask) if (train and n.dropout) else None
-                    lst.add(_lib.OP_HEAD_FWD, n.name, p=(self._aptr(n.x), mask, self._pptr(wkey), self._pptr(bkey), _vp(n.feat), _vp(n.logits)), head=hd,
+                    lst.add(_lib.OP_HEAD_FWD, n.name,
+                            p=(self._aptr(n.x), mask, self._pptr(wkey) if n.fc else None, self._pptr(bkey) if n.fc else None,
+                               _vp(n.feat), _vp(n.logits)), head=hd,
                             lane=L if train else lane_eval[n], reads=[ra(n.x)], writes=[('hd', id(n), 0, 1)])
                 bwd_groups.append(('head', n, hd))
+            elif n.kind == 'cb':
+                # conv (+bias) (+ReLU) without BatchNorm: the bias is the epilogue's shift (scale = 1), read from the fp32 master
+                d = self._conv_desc(n, N)
+                wk = _vp(self.Wsh, self.esize * n.w_off)
+                wT = _vp(self.Wsh, self.esize * n.wT_off)
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    Lx = L if train else lane_eval[n]
+                    if n.bias or n.relu:
+                        lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
+                                p=(self._aptr(n.x), wk, self._aptr(n.y), _vp(self.ones),
+                                   self._pptr(n.key + '.bias') if n.bias else _vp(self.zeros_k(n.K)), None),
+                                i=(0,), flags=4 if n.relu else 0, conv=d, lane=Lx, reads=[ra(n.x)], writes=[ra(n.y)])
+                    else:
+                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, self._aptr(n.y), None), conv=d, lane=Lx,
+                                reads=[ra(n.x)], writes=[ra(n.y)])
+                needs_dgrad = not n.x.buf.is_input
+                pack.add(_lib.OP_WEIGHT_PACK, n.name, p=(self._pptr(n.key + '.weight'), wk, wT if needs_dgrad else None),
+                         i=(n.K if n.K != n.K_real else 0,), conv=self._pack_desc(n, d))      # wT rows keep the PADDED stride
+                bwd_groups.append(('cb', n, d, wT, needs_dgrad))
+            elif n.kind == 'drop':
+                cnt = N * n.x.H * n.x.W * n.x.C
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    lst.add(_lib.OP_DROPOUT, n.name, p=(self._aptr(n.x), _vp(n.mask) if train else None, self._aptr(n.y)),
+                            i=(cnt, self.cdtype), f=(1.0 / (1.0 - n.p),), lane=L if train else lane_eval[n],
+                            reads=[ra(n.x), ('dm', id(n), 0, 1)], writes=[ra(n.y)])
+                bwd_groups.append(('drop', n, cnt))
+            elif n.kind == 'flat':
+                fi = (N, n.x.H * n.x.W, n.x.C, n.x.buf.C | (self.cdtype << 32))
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    lst.add(_lib.OP_FLATTEN_CHW, n.name, p=(self._aptr(n.x), self._aptr(n.y)), i=fi, flags=4,
+                            lane=L if train else lane_eval[n], reads=[ra(n.x)], writes=[ra(n.y)])
+                bwd_groups.append(('flat', n, fi))
+            elif n.kind == 'bnr':
+                # BatchNorm -> ReLU in FRONT of a conv, on a channel slice of a concatenation (densenet)
+                M = N * n.x.H * n.x.W
+                bkey = n.bn_key
+                bnd = BnDesc(M, n.K, n.x.buf.C, n.K, 1 if n.relu else 0, self.cdtype, n.eps, 0.1)
+                xp = self._aptr(n.x)
+                fwd_t.add(_lib.OP_BN_STATS, n.name, p=(xp, _vp(self.bn_part[L])), bn=bnd, lane=L, reads=[ra(n.x)], writes=[rbp(L)])
+                fwd_t.add(_lib.OP_BN_FINALIZE, n.name,
+                          p=(_vp(self.bn_part[L]), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
+                             _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
+                             self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3)),
+                          i=(self.ctx.lib.ifcbk_bn_stats_rows(M), n.K), bn=bnd, lane=L, reads=[rbp(L)], writes=[rst(n)])
+                for lst, train in ((fwd_t, True), (fwd_e, False)):
+                    lst.add(_lib.OP_BN_APPLY, n.name,
+                            p=(xp, self._stat(n, 2 if train else 4), self._stat(n, 3 if train else 5), None, self._aptr(n.y)),
+                            i=(0,), bn=bnd, lane=L if train else lane_eval[n], reads=[ra(n.x), rst(n)], writes=[ra(n.y)])
+                evalprep.add(_lib.OP_BN_FINALIZE, n.name,
+                             p=(None, self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
+                                _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
+                                None, None, self._stat(n, 4), self._stat(n, 5)), i=(0,), bn=bnd)
+                bwd_groups.append(('bnr', n, bnd))
 
         # backward in reverse node order, resolving first-writer / accumulate flags
         for g in reversed(bwd_groups):
@@ -803,9 +937,53 @@ class Engine:
                 acc = acc_flag(n.x.buf)
                 assert acc == 0, 'head must be the first writer of its input gradient'
                 bwd.add(_lib.OP_HEAD_BWD, n.name,
-                        p=(_vp(n.dlogits), _vp(n.feat), _vp(n.mask) if n.dropout else None, self._pptr(wkey),
-                           self._pptr(wkey, 'G'), self._pptr(bkey, 'G'), self._aptr(n.x, True)),
+                        p=(_vp(n.dlogits), _vp(n.feat), _vp(n.mask) if n.dropout else None, self._pptr(wkey) if n.fc else None,
+                           self._pptr(wkey, 'G') if n.fc else None, self._pptr(bkey, 'G') if n.fc else None, self._aptr(n.x, True)),
                         i=(n.x.buf.C,), head=hd, lane=lane_of[n], reads=[('hd', id(n), 0, 1)], writes=[rg(n.x)])
+            elif g[0] == 'cb':
+                _, n, d, wT, needs_dgrad = g
+                L = lane_of[n]
+                M = N * n.P * n.Q
+                dy, ldy = self._aptr(n.y, True), n.y.buf.C
+                if n.relu or n.bias:
+                    # dz = dy * (y > 0) in place, dbias = column sums of dz
+                    bnd = BnDesc(M, n.K, ldy, ldy, 1 if n.relu else 0, self.cdtype, 0.0, 0.0)
+                    bwd.add(_lib.OP_BIAS_RELU_BWD, n.name,
+                            p=(self._aptr(n.y), dy, dy if n.relu else None, self._pptr(n.key + '.bias', 'G') if n.bias else None),
+                            i=(ldy,), bn=bnd, lane=L, reads=[ra(n.y), rg(n.y)], writes=[rg(n.y)])
+                bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), dy, self._pptr(n.key + '.weight', 'G')), conv=d, lane=L,
+                        reads=[ra(n.x), rg(n.y)], writes=[])
+                if needs_dgrad:
+                    assert n.x.is_full
+                    acc = acc_flag(n.x.buf)
+                    bwd.add(_lib.OP_CONV_DGRAD, n.name, p=(dy, wT, self._aptr(n.x, True)), flags=acc, conv=d, lane=L,
+                            reads=[rg(n.y)], writes=[rg(n.x)])
+            elif g[0] == 'drop':
+                _, n, cnt = g
+                acc = acc_flag(n.x.buf)
+                bwd.add(_lib.OP_DROPOUT, n.name, p=(self._aptr(n.y, True), _vp(n.mask), self._aptr(n.x, True)), i=(cnt, self.cdtype),
+                        f=(1.0 / (1.0 - n.p),), flags=acc, lane=lane_of[n], reads=[rg(n.y), ('dm', id(n), 0, 1)], writes=[rg(n.x)])
+            elif g[0] == 'flat':
+                _, n, fi = g
+                assert n.x.is_full
+                acc = acc_flag(n.x.buf)
+                bwd.add(_lib.OP_FLATTEN_CHW, n.name, p=(self._aptr(n.x, True), self._aptr(n.y, True)), i=fi, flags=acc,
+                        lane=lane_of[n], reads=[rg(n.y)], writes=[rg(n.x)])
+            elif g[0] == 'bnr':
+                _, n, bnd = g
+                bkey = n.bn_key
+                # the slice's gradient: the FIRST backward op that touches the concatenation must cover all of it (densenet: the
+                # transition / norm5 that reads the whole block output); later (= earlier-in-forward) layers accumulate
+                first = n.x.buf.id not in written
+                if first:
+                    assert n.x.is_full, 'the first gradient written into a concatenation must cover all of it: ' + n.name
+                acc = acc_flag(n.x.buf)
+                bwd.add(_lib.OP_BN_BWD, n.name,
+                        p=(self._aptr(n.x), self._aptr(n.y), self._aptr(n.y, True), self._pptr(bkey + '.weight'),
+                           self._stat(n, 0), self._stat(n, 1), self._aptr(n.x, True), None, self._pptr(bkey + '.weight', 'G'),
+                           self._pptr(bkey + '.bias', 'G'), self._stat(n, 2), self._stat(n, 3)),
+                        i=(n.K, n.x.buf.C, 0), flags=8 if acc else 0, bn=bnd, lane=lane_of[n],
+                        reads=[ra(n.x), ra(n.y), rg(n.y), rst(n)], writes=[rg(n.x)])
             elif g[0] == 'pool':
                 _, n, pd, k = g
                 assert n.x.is_full
@@ -1004,14 +1182,18 @@ class Engine:
             return [(o.p[2] - base) // 4]
         if o.kind == _lib.OP_CONV_WGRAD_SEG:
             return [(o.p[2 + k] - base) // 4 for k in range(4) if o.i[k] > 0]
+        # (a vgg*_bn conv's bias rides with its BatchNorm's gradients: nothing writes it -- the batch mean absorbs the bias, its
+        # gradient is identically zero -- but the bucket plan must see the whole flat buffer covered)
         if o.kind == _lib.OP_BN_BWD:
-            return [(o.p[8] - base) // 4, (o.p[9] - base) // 4]
-        if o.kind == _lib.OP_BN_BWD_MAXPOOL:
-            return [(o.p[9] - base) // 4, (o.p[10] - base) // 4]
-        if o.kind == _lib.OP_BN_BWD_PARTIALS:
-            return [(o.p[9] - base) // 4, (o.p[10] - base) // 4]
+            g0 = (o.p[8] - base) // 4
+            return [g0, (o.p[9] - base) // 4] + self.cbias_after.get(g0, [])
+        if o.kind in (_lib.OP_BN_BWD_MAXPOOL, _lib.OP_BN_BWD_PARTIALS):
+            g0 = (o.p[9] - base) // 4
+            return [g0, (o.p[10] - base) // 4] + self.cbias_after.get(g0, [])
         if o.kind == _lib.OP_HEAD_BWD:
-            return [(o.p[4] - base) // 4, (o.p[5] - base) // 4]
+            return [(o.p[4] - base) // 4, (o.p[5] - base) // 4] if o.p[4] else []
+        if o.kind == _lib.OP_BIAS_RELU_BWD:
+            return [(o.p[3] - base) // 4] if o.p[3] else []
         return []
 
     def ddp_segments(self, pl, nseg=8):
@@ -1020,7 +1202,7 @@ class Engine:
         if pl.ddp_segs is not None:
             return pl.ddp_segs
         from .dp import segment_plan
-        padded = {o: (n + 3) // 4 * 4 for (o, n, _s, _k, _n) in self.poff.values()}
+        padded = self.palloc
         ops = pl.bwd_list.ops
         segs = []
         for (b0, b1, lo, hi) in segment_plan([self._op_param_offsets(o) for o in ops], padded, self.nparam_padded, nseg):
@@ -1107,13 +1289,24 @@ class Engine:
         return n
 
     def make_dropout_mask(self, N):
+        ext = self.external_mask
         for h in self.heads:
             if h.dropout:
-                if self.external_mask is not None:
-                    h.mask[:N].copy_(self.external_mask[:N].to(torch.uint8))
+                if ext is not None and not isinstance(ext, dict):
+                    h.mask[:N].copy_(ext[:N].to(torch.uint8))
+                elif isinstance(ext, dict) and h.name in ext:
+                    h.mask[:N].copy_(ext[h.name][:N].to(torch.uint8))
                 else:
                     self.ctx.call('ifcbk_dropout_mask', _vp(h.mask), N * h.C, 0.5, self.dropout_seed,
                                   self.dropout_calls * (1 << 24), self.stream())
+        for k, n in enumerate(self.drops):
+            # nn.Dropout layers of a classifier stack (alexnet / vgg / squeezenet): one keep-mask per layer and step; a parity
+            # test hands masks over as {node name: [B, H*W*C] in NHWC element order}
+            if isinstance(ext, dict) and n.name in ext:
+                n.mask[:N].copy_(ext[n.name][:N].reshape(N, -1).to(torch.uint8))
+            else:
+                self.ctx.call('ifcbk_dropout_mask', _vp(n.mask), N * n.mask.shape[1], float(n.p),
+                              self.dropout_seed + 0x9E3779B1 * (k + 1), self.dropout_calls * (1 << 26), self.stream())
         self.dropout_calls += 1
 
     def forward_train(self, N):

@@ -69,10 +69,12 @@ class HipBackbone(nn.Module):
             mod, leaf = self._submodule(key)
             mod.register_buffer(leaf, eng.bviews[key])
             if leaf == 'running_var':
-                mod.register_buffer('num_batches_tracked', eng.nbt[eng.convs.index(node)])
+                mod.register_buffer('num_batches_tracked', eng.nbt[eng.bn_index[node]])
         object.__setattr__(self, '_hook', torch.zeros(1, device=eng.dev, requires_grad=True))
         object.__setattr__(self, '_train_heads', sorted(eng.heads, key=lambda h: h.aux))
         self.num_classes = net.NC
+        if self._cbias_pairs():
+            self._register_load_state_dict_pre_hook(self._cbias_pre_hook)
         eng.init_weights()
 
     def _submodule(self, key):
@@ -89,13 +91,35 @@ class HipBackbone(nn.Module):
         super()._load_from_state_dict(*a, **k)
         self.engine.params_changed()
 
+    # vgg*_bn: Conv2d(bias=True) -> BatchNorm2d.  The batch mean absorbs the bias, so the engine convolves without it and its
+    # running_mean tracks the bias-free conv output; the state_dict shows torchvision's tensor (mean of conv + bias).
+    def _cbias_pairs(self):
+        return [(n.conv_key + '.bias', n.bn_key + '.running_mean') for n in self.engine.convs if getattr(n, 'conv_bias', False)]
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        prefix = k.get('prefix', a[1] if len(a) > 1 else '')
+        for bk, rk in self._cbias_pairs():
+            if prefix + rk in sd and prefix + bk in sd:
+                sd[prefix + rk] = sd[prefix + rk] + sd[prefix + bk].to(sd[prefix + rk].device)
+        return sd
+
+    def _cbias_pre_hook(self, state_dict, prefix, *unused):
+        # runs inside load_state_dict (direct or through a parent module) before this module's tensors are copied; the dict is
+        # load_state_dict's own shallow copy
+        for bk, rk in self._cbias_pairs():
+            if prefix + bk in state_dict and prefix + rk in state_dict:
+                rm = state_dict[prefix + rk]
+                state_dict[prefix + rk] = rm - state_dict[prefix + bk].to(rm.device)
+
     def load_state_dict(self, state_dict, strict=True):
         r = super().load_state_dict(state_dict, strict)
         self.engine.params_changed()
         return r
 
     def set_dropout_mask(self, mask):
-        """parity hook: fix the Bernoulli keep-mask [B,2048] of the train-mode dropout (None = generate)."""
+        """parity hook: fix the Bernoulli keep-mask of the train-mode dropout (None = generate): a [B, 2048] tensor for
+        inception_v3's head, or {node name: [B, features]} for the nn.Dropout layers of alexnet / vgg / squeezenet."""
         self.engine.external_mask = mask
 
     def forward(self, x):
@@ -199,13 +223,12 @@ def load_pretrained_weights(backbone, path):
 
 
 def get_namebrand_model(model_name, num_o_classes, pretrained=False, device=0, max_batch=None, dtype='bf16', **engine_kw):
-    """``neuston_models.py:22-45``.  Backbones on the HIP path: inception_v3, resnet18/34/50/101/152.
+    """``neuston_models.py:22-45``.  Backbones on the HIP path: every family the reference accepts -- inception_v3, alexnet,
+    squeezenet (1_1), vgg11/13/16/19(_bn), resnet18/34/50/101/152, densenet121/161/169/201.
     ``pretrained=True`` cannot download ImageNet weights here (no torchvision / network): it switches on
     inception's ``transform_input`` exactly as torchvision does and expects a ``load_state_dict`` to follow.
-    Names the reference accepts but this path does not implement raise ``NotImplementedError``; names the
-    reference rejects raise its ``KeyError("model unknown!")``."""
-    if model_name in ('alexnet', 'squeezenet') or model_name.startswith(('vgg', 'densenet')):
-        raise NotImplementedError('%s is accepted by the reference but not built on the MI355X path yet' % model_name)
+    Names the reference rejects raise its ``KeyError("model unknown!")`` (``AttributeError`` for a vgg* / densenet* name
+    torchvision does not have, as ``getattr(torchvision.models, name)`` would)."""
     net = graph.build(model_name, num_o_classes, pretrained)
     return HipBackbone(net, device, max_batch, dtype, **engine_kw)
 

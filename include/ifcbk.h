@@ -140,7 +140,9 @@ int ifcbk_bn_apply(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const float*
                    const float* shift, const void* residual, int ldr, void* y, void* stream);
 /* dz = dy * (y>0 if relu);  dgamma = sum dz*xhat;  dbeta = sum dz;
  * dx = gamma*invstd*(dz - dbeta/M - xhat*dgamma/M); if dres!=NULL: dres (+)= dz (residual branch).
- * dy may alias dx.  Partial sums go through the ctx workspace (deterministic two-stage reduction).      */
+ * dy may alias dx.  Partial sums go through the ctx workspace (deterministic two-stage reduction).
+ * dres_accumulate: bit 0 = dres += dz, bit 1 = dx accumulates too (a BatchNorm in FRONT of a conv reading a slice of a
+ * concatenation, densenet: the slice's gradient collects the share of every later layer).                */
 int ifcbk_bn_bwd(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* y, const void* dy, int lddy,
                  const float* gamma, const float* mean, const float* invstd,
                  void* dx, int lddx, void* dres, int lddres, int dres_accumulate,
@@ -284,6 +286,25 @@ int ifcbk_bn_bwd_partials_ld(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, co
                              const float* shift, const float* part, int ntiles, int part_ld, void* dx, int lddx,
                              float* dgamma, float* dbeta, int param_accumulate, void* stream);
 
+/* ------------------------------------------------------------------ layers without BatchNorm (alexnet, vgg*, squeezenet1_1,
+ * densenet*: neuston_models.py:27-36,40-42 -> torchvision alexnet.py / vgg.py / squeezenet.py / densenet.py).  The conv with its
+ * bias (+ReLU) is ifcbk_conv2d_fwd_affine with scale = 1, shift = bias; these are the passes around it.                           */
+/* autograd of relu_(conv(x) + b) up to the conv: dz = dy * (y > 0) (relu = 0: dz = dy), dbias (+)= column sums of dz.  y, dy, dz:
+ * [M] rows of K channels with row strides ldy / lddy / lddz (elements); dz may alias dy and may be NULL (sums only), dbias may be
+ * NULL (mask only).  Deterministic two-stage sums through the ctx workspace (ifcbk_bias_relu_bwd_workspace bytes).              */
+int ifcbk_bias_relu_bwd(ifcbk_ctx*, int64_t M, int K, int dtype, const void* y, int ldy, const void* dy, int lddy, void* dz,
+                        int lddz, int relu, float* dbias, int param_accumulate, void* stream);
+size_t ifcbk_bias_relu_bwd_workspace(int64_t M, int K);
+int ifcbk_bias_relu_bwd_rows(int64_t M);
+/* nn.Dropout forward and backward: y (+)= x * (mask ? mask[i] * scale : 1) over n contiguous elements (mask: one byte each,
+ * ifcbk_dropout_mask; NULL = eval mode, a copy)                                                                                    */
+int ifcbk_dropout_apply(ifcbk_ctx*, int64_t n, int dtype, const void* x, const uint8_t* mask, float scale, void* y, int accumulate,
+                        void* stream);
+/* torch.flatten(x, 1) of an NCHW tensor, on the NHWC activation x [N][HW] rows of C channels (row stride ldx):
+ * to_chw = 1: flat[n][c*HW + hw] = x[n][hw][c];  to_chw = 0 (backward): x[n][hw][c] (+)= flat[n][c*HW + hw]                          */
+int ifcbk_flatten_chw(ifcbk_ctx*, int N, int HW, int C, int dtype, void* x, int ldx, void* flat, int to_chw, int accumulate,
+                      void* stream);
+
 /* ------------------------------------------------------------------ program runner
  * One call launches a whole forward / backward / update list: the host builds the op table once
  * (static graph), so the per-step host cost is one FFI crossing.                                     */
@@ -297,11 +318,14 @@ enum {
     IFCBK_OP_CONV_DGRAD_BNSTAT, IFCBK_OP_BN_BWD_PARTIALS, IFCBK_OP_BN_STATS, IFCBK_OP_AVGPOOL_AFFINE,
     IFCBK_OP_CONV_FWD_AFFINE_SEG,
     IFCBK_OP_SGD,            /* p: P, G, momentum buffer (nullable); i[0] = n; f: lr, momentum, weight decay, grad scale */
-    IFCBK_OP_CONV_DGRAD_BNSTAT_TAB   /* p: dy, wT, dx, table, part (ifcbk_conv2d_dgrad_bnstat_table)                           */
+    IFCBK_OP_CONV_DGRAD_BNSTAT_TAB,  /* p: dy, wT, dx, table, part (ifcbk_conv2d_dgrad_bnstat_table)                           */
+    IFCBK_OP_BIAS_RELU_BWD,  /* p: y, dy, dz, dbias; u.bn: M, C, ldx = ld(y), ldy = ld(dy), relu, dtype; i[0] = ld(dz)          */
+    IFCBK_OP_DROPOUT,        /* p: x, mask (nullable), y; i[0] = n, i[1] = dtype; f[0] = scale; flags bit 0 accumulate           */
+    IFCBK_OP_FLATTEN_CHW     /* p: x, flat; i: N, HW, C, ldx | dtype << 32; flags bit 0 accumulate, bit 2 to_chw                 */
 };
 typedef struct {
     int32_t kind;
-    int32_t flags;           /* bit 0 accumulate, bit 1 param accumulate, bit 2 relu (per kind);
+    int32_t flags;           /* bit 0 accumulate, bit 1 param accumulate, bit 2 relu (per kind), bit 3 dx accumulate (BN_BWD);
                               * bits 8-9 LANE of this op (0 = the caller's stream, 1-3 = ctx-owned streams),
                               * bits 12-15 WAIT mask: lanes whose queued work must finish before this op starts.
                               * All lanes start after the caller's prior work and join lane 0 at program end. */

@@ -366,8 +366,269 @@ _RESNETS = {'resnet18': (BasicBlock, [2, 2, 2, 2]), 'resnet34': (BasicBlock, [3,
             'resnet152': (Bottleneck, [3, 8, 36, 3])}
 
 
+# ------------------------------------------------------------------------------------------ alexnet / vgg / squeezenet / densenet
+# (reference call sites neuston_models.py:27-36,40-42; torchvision 0.8.2 alexnet.py, vgg.py, squeezenet.py, densenet.py restated
+# from their published architectures; pinned by the published parameter totals in tests/test_oracle_cpu.py)
+def _drop(st, x, masks, name, training, p=0.5):
+    """nn.Dropout with an optional fixed keep-mask (parity tests); the HIP path stores the result"""
+    if not training:
+        return x
+    if masks is not None and name in masks:
+        return st.act(x * masks[name].to(x.dtype).reshape(x.shape) * (1.0 / (1.0 - p)))
+    return st.act(F.dropout(x, p, True))
+
+
+def _cbr(st, conv, x, relu=True):
+    """conv + bias (+ReLU) as ONE stored tensor (the HIP epilogue adds the fp32 bias to the fp32 accumulator, then rounds)"""
+    y = F.conv2d(x, st.weight(conv.weight), conv.bias, conv.stride, conv.padding)
+    return st.act(F.relu(y) if relu else y)
+
+
+def _lin(st, lin, x, relu=True):
+    y = F.linear(x, st.weight(lin.weight), lin.bias)
+    return st.act(F.relu(y) if relu else y)
+
+
+class AlexNet(nn.Module):
+    def __init__(self, num_classes=1000, storage='fp32'):
+        super().__init__()
+        self.st = Storage(storage)
+        self.dropout_masks = None
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64, 11, 4, 2), nn.ReLU(True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(True),
+            nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(True),
+            nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(True), nn.MaxPool2d(3, 2))
+        self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
+        self.classifier = nn.Sequential(nn.Dropout(), nn.Linear(256 * 6 * 6, 4096), nn.ReLU(True), nn.Dropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(True), nn.Linear(4096, num_classes))
+
+    def forward(self, x):
+        st, f, c = self.st, self.features, self.classifier
+        x = st.act(x)
+        x = F.max_pool2d(_cbr(st, f[0], x), 3, 2)
+        x = F.max_pool2d(_cbr(st, f[3], x), 3, 2)
+        x = _cbr(st, f[6], x)
+        x = _cbr(st, f[8], x)
+        x = F.max_pool2d(_cbr(st, f[10], x), 3, 2)
+        x = torch.flatten(self.avgpool(x), 1)
+        x = _drop(st, x, self.dropout_masks, 'classifier.drop0', self.training)
+        x = _lin(st, c[1], x)
+        x = _drop(st, x, self.dropout_masks, 'classifier.drop1', self.training)
+        x = _lin(st, c[4], x)
+        return c[6](x)
+
+
+_VGG_CFG = {'11': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+            '13': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512, 'M'],
+            '16': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M'],
+            '19': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']}
+
+
+class VGG(nn.Module):
+    def __init__(self, cfg, batch_norm, num_classes=1000, storage='fp32'):
+        super().__init__()
+        self.st = Storage(storage)
+        self.dropout_masks = None
+        layers, cin = [], 3
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers.append(nn.Conv2d(cin, v, 3, padding=1))
+                if batch_norm:
+                    layers.append(nn.BatchNorm2d(v))
+                layers.append(nn.ReLU(True))
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096),
+                                        nn.ReLU(True), nn.Dropout(), nn.Linear(4096, num_classes))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        st, c = self.st, self.classifier
+        x = st.act(x)
+        mods = list(self.features)
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            if isinstance(m, nn.MaxPool2d):
+                x = F.max_pool2d(x, 2, 2)
+                k += 1
+            elif k + 1 < len(mods) and isinstance(mods[k + 1], nn.BatchNorm2d):
+                # conv (+bias) -> BN -> ReLU: the raw conv output and the activation are both stored
+                y = st.act(F.conv2d(x, st.weight(m.weight), m.bias, m.stride, m.padding))
+                x = st.act(F.relu(mods[k + 1](y)))
+                k += 3
+            else:
+                x = _cbr(st, m, x)
+                k += 2
+        x = torch.flatten(self.avgpool(x), 1)
+        x = _lin(st, c[0], x)
+        x = _drop(st, x, self.dropout_masks, 'classifier.drop0', self.training)
+        x = _lin(st, c[3], x)
+        x = _drop(st, x, self.dropout_masks, 'classifier.drop1', self.training)
+        return c[6](x)
+
+
+class Fire(nn.Module):
+    def __init__(self, st, cin, sq, e1, e3):
+        super().__init__()
+        self.st = st
+        self.squeeze = nn.Conv2d(cin, sq, 1)
+        self.squeeze_activation = nn.ReLU(True)
+        self.expand1x1 = nn.Conv2d(sq, e1, 1)
+        self.expand1x1_activation = nn.ReLU(True)
+        self.expand3x3 = nn.Conv2d(sq, e3, 3, padding=1)
+        self.expand3x3_activation = nn.ReLU(True)
+
+    def forward(self, x):
+        s = _cbr(self.st, self.squeeze, x)
+        return torch.cat([_cbr(self.st, self.expand1x1, s), _cbr(self.st, self.expand3x3, s)], 1)
+
+
+class SqueezeNet11(nn.Module):
+    def __init__(self, num_classes=1000, storage='fp32'):
+        super().__init__()
+        st = self.st = Storage(storage)
+        self.dropout_masks = None
+        self.num_classes = num_classes
+        self.features = nn.Sequential(
+            nn.Conv2d(3, 64, 3, 2), nn.ReLU(True), nn.MaxPool2d(3, 2, ceil_mode=True),
+            Fire(st, 64, 16, 64, 64), Fire(st, 128, 16, 64, 64), nn.MaxPool2d(3, 2, ceil_mode=True),
+            Fire(st, 128, 32, 128, 128), Fire(st, 256, 32, 128, 128), nn.MaxPool2d(3, 2, ceil_mode=True),
+            Fire(st, 256, 48, 192, 192), Fire(st, 384, 48, 192, 192), Fire(st, 384, 64, 256, 256), Fire(st, 512, 64, 256, 256))
+        final_conv = nn.Conv2d(512, num_classes, 1)
+        self.classifier = nn.Sequential(nn.Dropout(0.5), final_conv, nn.ReLU(True), nn.AdaptiveAvgPool2d((1, 1)))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                if m is final_conv:
+                    nn.init.normal_(m.weight, 0.0, 0.01)
+                else:
+                    nn.init.kaiming_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        st, f = self.st, self.features
+        x = st.act(x)
+        x = F.max_pool2d(_cbr(st, f[0], x), 3, 2, ceil_mode=True)
+        x = f[4](f[3](x))
+        x = F.max_pool2d(x, 3, 2, ceil_mode=True)
+        x = f[7](f[6](x))
+        x = F.max_pool2d(x, 3, 2, ceil_mode=True)
+        x = f[12](f[11](f[10](f[9](x))))
+        x = _drop(st, x, self.dropout_masks, 'classifier.0', self.training)
+        x = _cbr(st, self.classifier[1], x)
+        return torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, st, cin, growth, bn_size):
+        super().__init__()
+        self.st = st
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, feats):
+        st = self.st
+        x = torch.cat(feats, 1)
+        t = st.act(F.relu(self.norm1(x)))
+        t = st.act(_cv(st, self.conv1, t))
+        t = st.act(F.relu(self.norm2(t)))
+        return st.act(_cv(st, self.conv2, t))
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, st, nl, cin, bn_size, growth):
+        super().__init__()
+        for i in range(nl):
+            self.add_module('denselayer%d' % (i + 1), _DenseLayer(st, cin + i * growth, growth, bn_size))
+
+    def forward(self, x):
+        feats = [x]
+        for _name, layer in self.items():
+            feats.append(layer(feats))
+        return torch.cat(feats, 1)
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, st, cin, cout):
+        super().__init__()
+        self.st = st
+        self.add_module('norm', nn.BatchNorm2d(cin))
+        self.add_module('relu', nn.ReLU(True))
+        self.add_module('conv', nn.Conv2d(cin, cout, 1, bias=False))
+        self.add_module('pool', nn.AvgPool2d(2, 2))
+
+    def forward(self, x):
+        st = self.st
+        t = st.act(F.relu(self.norm(x)))
+        t = st.act(_cv(st, self.conv, t))
+        return st.act(F.avg_pool2d(t, 2, 2))
+
+
+class DenseNet(nn.Module):
+    def __init__(self, growth, blocks, c0, bn_size=4, num_classes=1000, storage='fp32'):
+        super().__init__()
+        st = self.st = Storage(storage)
+        self.features = nn.Sequential()
+        self.features.add_module('conv0', nn.Conv2d(3, c0, 7, 2, 3, bias=False))
+        self.features.add_module('norm0', nn.BatchNorm2d(c0))
+        self.features.add_module('relu0', nn.ReLU(True))
+        self.features.add_module('pool0', nn.MaxPool2d(3, 2, 1))
+        nf = c0
+        for i, nl in enumerate(blocks):
+            self.features.add_module('denseblock%d' % (i + 1), _DenseBlock(st, nl, nf, bn_size, growth))
+            nf += nl * growth
+            if i != len(blocks) - 1:
+                self.features.add_module('transition%d' % (i + 1), _Transition(st, nf, nf // 2))
+                nf //= 2
+        self.features.add_module('norm5', nn.BatchNorm2d(nf))
+        self.classifier = nn.Linear(nf, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        st, f = self.st, self.features
+        x = st.act(x)
+        x = st.act(_cv(st, f.conv0, x))
+        x = st.act(F.relu(f.norm0(x)))
+        x = F.max_pool2d(x, 3, 2, 1)
+        for name, m in f.named_children():
+            if name.startswith(('denseblock', 'transition')):
+                x = m(x)
+        x = st.act(F.relu(f.norm5(x)))
+        x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+        return self.classifier(x)
+
+
+_DENSENETS = {'densenet121': (32, (6, 12, 24, 16), 64), 'densenet161': (48, (6, 12, 36, 24), 96),
+              'densenet169': (32, (6, 12, 32, 32), 64), 'densenet201': (32, (6, 12, 48, 32), 64)}
+
+
 def get_namebrand_model(model_name, num_o_classes, pretrained=False, storage='fp32'):
-    """Oracle twin of ``/root/reference/neuston_models.py:22-45`` for the backbones on the hot path.
+    """Oracle twin of ``/root/reference/neuston_models.py:22-45`` for every backbone family the reference accepts.
 
     ``pretrained=True`` only switches on inception's ``transform_input`` (what torchvision does when it
     loads ImageNet weights); no weights are downloaded -- callers load an explicit ``state_dict``.
@@ -380,6 +641,20 @@ def get_namebrand_model(model_name, num_o_classes, pretrained=False, storage='fp
         block, layers = _RESNETS[model_name]
         model = ResNet(block, layers, 1000, storage=storage)
         model.fc = nn.Linear(model.fc.in_features, num_o_classes)
+    elif model_name == 'alexnet':
+        model = AlexNet(1000, storage=storage)
+        model.classifier[6] = nn.Linear(model.classifier[6].in_features, num_o_classes)
+    elif model_name == 'squeezenet':
+        model = SqueezeNet11(1000, storage=storage)
+        model.classifier[1] = nn.Conv2d(512, num_o_classes, kernel_size=(1, 1), stride=(1, 1))
+        model.num_classes = num_o_classes
+    elif model_name.startswith('vgg') and model_name[3:5] in _VGG_CFG and model_name[5:] in ('', '_bn'):
+        model = VGG(_VGG_CFG[model_name[3:5]], model_name.endswith('_bn'), 1000, storage=storage)
+        model.classifier[6] = nn.Linear(model.classifier[6].in_features, num_o_classes)
+    elif model_name in _DENSENETS:
+        growth, blocks, c0 = _DENSENETS[model_name]
+        model = DenseNet(growth, blocks, c0, 4, 1000, storage=storage)
+        model.classifier = nn.Linear(model.classifier.in_features, num_o_classes)
     else:
         raise KeyError("model unknown!")
     return model

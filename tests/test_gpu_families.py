@@ -1,0 +1,245 @@
+"""The backbone families of ``get_namebrand_model`` beyond inception_v3 / resnet (reference: neuston_models.py:27-36,40-42):
+alexnet, vgg* (with and without BatchNorm), squeezenet1_1, densenet*.  Each is run on the HIP path and compared with the CPU
+oracle's restatement of torchvision 0.8.2 on identical weights, inputs, labels and dropout masks:
+
+* fp32 parity mode against the reference's own fp32 arithmetic: train-mode logits, loss, EVERY parameter gradient, the BatchNorm
+  running statistics, and the eval-mode logits (north_star tolerance 1e-3 on the logits);
+* bf16 (the benchmarked storage type) against the oracle with bf16 rounding at the points where the HIP path stores a tensor.
+
+The networks without BatchNorm are not chaotic, so end-to-end gradients are compared tightly; vgg*_bn / densenet* keep the
+looser end-to-end gradient bound of the inception / resnet tests (random-init BatchNorm stacks amplify rounding).
+The C-ABI entry points these families added (bias+ReLU backward, dropout, flatten) are checked one by one against torch."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from local_parity import rel
+
+pytestmark = pytest.mark.gpu
+
+#            name          classes batch  has BatchNorm
+CASES = [('alexnet', 5, 4, False), ('vgg11', 4, 2, False), ('vgg13_bn', 4, 3, True), ('squeezenet', 6, 4, False),
+         ('densenet121', 5, 3, True)]
+
+
+def _pair(name, nc, B, dtype, seed=0):
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    from oracle import tv_models
+    torch.manual_seed(seed)
+    hip = get_namebrand_model(name, nc, max_batch=B, dtype=dtype)
+    if name.endswith('_bn'):
+        # give the conv biases in front of the BatchNorms non-zero values: torchvision initialises them to 0, a trained
+        # checkpoint does not have them at 0
+        sd = hip.state_dict()
+        g = torch.Generator().manual_seed(seed + 1)
+        for k in list(sd):
+            if k.startswith('features.') and k.endswith('.bias') and sd[k].numel() and (k[:-4] + 'weight') in sd and sd[k[:-4] + 'weight'].dim() == 4:
+                sd[k] = (torch.rand(sd[k].shape, generator=g) - 0.5).to(sd[k].device)
+        hip.load_state_dict(sd)
+    sd = {k: v.detach().cpu().clone() for k, v in hip.state_dict().items()}
+    ora = tv_models.get_namebrand_model(name, nc, storage='fp32' if dtype == 'fp32' else 'bf16')
+    ora.load_state_dict(sd, strict=True)
+    return hip, ora
+
+
+def _masks(name, B, g):
+    """(oracle masks in the reference's element order, HIP masks in NHWC element order)"""
+    if name == 'alexnet':
+        m = {'classifier.drop0': torch.rand(B, 9216, generator=g) > 0.5, 'classifier.drop1': torch.rand(B, 4096, generator=g) > 0.5}
+        return m, {k: v.cuda() for k, v in m.items()}
+    if name.startswith('vgg'):
+        m = {'classifier.drop0': torch.rand(B, 4096, generator=g) > 0.5, 'classifier.drop1': torch.rand(B, 4096, generator=g) > 0.5}
+        return m, {k: v.cuda() for k, v in m.items()}
+    if name == 'squeezenet':
+        m = torch.rand(B, 512, 13, 13, generator=g) > 0.5
+        return {'classifier.0': m}, {'classifier.0': m.permute(0, 2, 3, 1).reshape(B, -1).contiguous().cuda()}
+    return None, None
+
+
+def _step(name, nc, B, dtype):
+    hip, ora = _pair(name, nc, B, dtype)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, nc, (B,), generator=g)
+    mo, mh = _masks(name, B, g)
+    if mo is not None:
+        ora.dropout_masks = mo
+        hip.set_dropout_mask(mh)
+    hip.train(); ora.train()
+    out_h = hip(x.cuda())
+    out_o = ora(x)
+    loss_h = F.cross_entropy(out_h, y.cuda())
+    loss_o = F.cross_entropy(out_o, y)
+    loss_h.backward()
+    loss_o.backward()
+    torch.cuda.synchronize()
+    return hip, ora, x, out_h.detach().cpu(), out_o.detach(), loss_h.item(), loss_o.item()
+
+
+def _grad_errors(hip, ora, noise=1e-4):
+    op = dict(ora.named_parameters())
+    errs, dead = {}, []
+    gmax = max(float(p.grad.abs().max()) for p in op.values())
+    absorbed = {n.conv_key + '.bias' for n in hip.engine.convs if getattr(n, 'conv_bias', False)}
+    for k, p in hip.named_parameters():
+        go, gh = op[k].grad, p.grad.cpu()
+        if k in absorbed:
+            # a conv bias in front of a BatchNorm: its true gradient is zero (the batch mean absorbs the bias), autograd returns
+            # rounding noise; the HIP path returns exact zeros
+            dead.append(k)
+            # (under bf16 storage autograd's 'zero' is the sum of ~150 k rounded gradient elements: a few percent of the largest
+            # gradient; nothing to compare it with)
+            assert (noise is None or float(go.abs().max()) < noise * gmax) and float(gh.abs().max()) == 0.0, k
+            continue
+        errs[k] = rel(gh, go)
+    return errs, dead
+
+
+@pytest.mark.parametrize('name,nc,B,bn', CASES)
+def test_family_fp32_parity_with_the_reference_arithmetic(name, nc, B, bn):
+    hip, ora, x, lh, lo, loss_h, loss_o = _step(name, nc, B, 'fp32')
+    r = rel(lh, lo)
+    print(name, 'fp32 train logits rel %.2e, loss %.6f vs %.6f' % (r, loss_h, loss_o))
+    assert r < 1e-3
+    assert abs(loss_h - loss_o) < 1e-4 * abs(loss_o)
+    errs, dead = _grad_errors(hip, ora)
+    worst = max(errs, key=errs.get)
+    print(name, 'fp32 parameter gradients: worst tensor', worst, '%.2e' % errs[worst], '| zero-gradient biases:', len(dead))
+    # (without BatchNorm the gradients agree to ~2e-6 -- alexnet -- unless a max pool's two largest window elements differ by less
+    # than the 1e-6 forward distance: the arg-max then flips and one gradient element takes the other route.  vgg11 at batch 2
+    # has 2 such elements among 800 k behind features.15 (scripts/dbg_vgg_acts.py), worth 2e-3 of the gradient norm)
+    med = sorted(errs.values())[len(errs) // 2]
+    print(name, 'median tensor %.2e' % med)
+    # (densenet121: 121 random-init BatchNorm layers behind a max pool; the first BatchNorm's gradient collects all of it)
+    assert errs[worst] < (0.15 if name.startswith('densenet') else 5e-2 if bn else 1e-2) and med < (2e-2 if bn else 1e-3)
+    if bn:
+        assert len(dead) == sum(1 for n in hip.engine.convs if getattr(n, 'conv_bias', False))
+        ob = dict(ora.named_buffers())
+        for k, b in hip.state_dict().items():
+            if k.endswith(('running_mean', 'running_var')):
+                assert rel(b.cpu(), ob[k]) < 1e-4, k
+            if k.endswith('num_batches_tracked'):
+                assert int(b) == 1
+    hip.eval(); ora.eval()
+    with torch.no_grad():
+        r = rel(hip(x.cuda()).cpu(), ora(x))
+    print(name, 'fp32 eval logits rel %.2e' % r)
+    assert r < 1e-3
+
+
+@pytest.mark.parametrize('name,nc,B,bn', CASES)
+def test_family_bf16_against_the_bf16_storage_oracle(name, nc, B, bn):
+    hip, ora, x, lh, lo, loss_h, loss_o = _step(name, nc, B, 'bf16')
+    r = rel(lh, lo)
+    print(name, 'bf16 train logits rel %.2e, loss %.5f vs %.5f' % (r, loss_h, loss_o))
+    assert r < (0.25 if bn else 2e-2)
+    assert abs(loss_h - loss_o) < (0.1 if bn else 1e-2) * abs(loss_o)
+    errs, dead = _grad_errors(hip, ora, None)
+    worst = max(errs, key=errs.get)
+    print(name, 'bf16 parameter gradients: worst tensor', worst, '%.2e' % errs[worst])
+    med = sorted(errs.values())[len(errs) // 2]
+    print(name, 'median tensor %.2e' % med)
+    # bf16 activations sit on an 8-bit grid: two elements of a pooling window are often equal or one ulp apart, so the two
+    # implementations (different fp32 summation orders in front of the rounding) take different arg-max / ReLU routes for a
+    # fraction of the gradient elements -- individually large, statistically equivalent differences that grow towards the
+    # first layers.  The sharp comparison is the fp32 test above (same kernels, T = float); this one bounds the bf16 drift.
+    if not bn:
+        assert errs[worst] < 0.4 and med < 0.2
+    hip.eval(); ora.eval()
+    with torch.no_grad():
+        eh, eo = hip(x.cuda()).cpu(), ora(x)
+    r = rel(eh, eo)
+    print(name, 'bf16 eval logits rel %.2e' % r)
+    assert r < (0.1 if bn else 4e-2)
+    # RUN mode replays the eval forward as a hipGraph: the second call is the replay
+    with torch.no_grad():
+        assert torch.equal(hip(x.cuda()).cpu(), eh)
+    assert 'fwd_eval' in hip.engine.plan(B).graphs
+
+
+def test_fused_train_step_learns_on_every_family():
+    """six fused steps (forward + loss + backward + Adam + repack as one program) on one batch: the loss falls"""
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    for name, nc, B, bn in CASES:
+        torch.manual_seed(3)
+        # (lr 1e-4: with the reference's Adam(1e-3) a freshly initialised vgg13_bn diverges on such a batch -- in the reference's
+        # own arithmetic too: the oracle's losses are 1.37, 11.8, 58, 160)
+        hip = get_namebrand_model(name, nc, max_batch=B, lr=1e-4)
+        eng = hip.engine
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(B, 3, 224, 224, generator=g).cuda()
+        y = torch.randint(0, nc, (B,), generator=g)
+        losses = []
+        for _ in range(6):
+            eng.load_input_nchw(x)
+            eng.target[:B].copy_(y)
+            eng.train_step(B)
+            losses.append(float(eng.loss))
+        print(name, 'fused-step losses', ['%.4f' % v for v in losses])
+        assert all(l == l for l in losses) and losses[-1] < losses[0], (name, losses)
+        del hip, eng
+        torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- C-ABI units
+@pytest.mark.parametrize('M,K,ld,relu,dtype', [(1000, 64, 64, 1, 'bf16'), (37, 4096, 4096, 1, 'bf16'), (5000, 24, 40, 1, 'f32'),
+                                               (300, 104, 104, 0, 'bf16'), (70000, 16, 16, 1, 'bf16')])
+def test_bias_relu_bwd_vs_torch(ctx, M, K, ld, relu, dtype):
+    from ifcb_classifier_amd import _lib
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = torch.Generator().manual_seed(M + K)
+    y = torch.randn(M, ld, generator=g).to(td).cuda()
+    dy = torch.randn(M, ld, generator=g).to(td).cuda()
+    dz = torch.zeros(M, ld, dtype=td, device='cuda')
+    db = torch.full((K,), 7.0, device='cuda')
+    ctx.reserve(ctx.lib.ifcbk_bias_relu_bwd_workspace(M, K))
+    ctx.call('ifcbk_bias_relu_bwd', M, K, _lib.BF16 if dtype == 'bf16' else _lib.F32, _lib.ptr(y), ld, _lib.ptr(dy), ld,
+             _lib.ptr(dz), ld, relu, _lib.ptr(db), 0, _lib.cur_stream())
+    torch.cuda.synchronize()
+    want = dy[:, :K].float() * ((y[:, :K].float() > 0) if relu else 1.0)
+    assert torch.equal(dz[:, :K].float(), want.to(td).float())
+    assert (dz[:, K:] == 0).all()
+    assert rel(db.cpu(), want.sum(0).cpu()) < 1e-5
+    # accumulate into the parameter gradient, mask in place
+    ctx.call('ifcbk_bias_relu_bwd', M, K, _lib.BF16 if dtype == 'bf16' else _lib.F32, _lib.ptr(y), ld, _lib.ptr(dy), ld,
+             _lib.ptr(dy), ld, relu, _lib.ptr(db), 1, _lib.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dy[:, :K], dz[:, :K])
+    assert rel(db.cpu(), 2 * want.sum(0).cpu()) < 1e-5
+
+
+def test_dropout_apply_and_flatten_chw_vs_torch(ctx):
+    from ifcb_classifier_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    n = 8 * 1234
+    x = torch.randn(n, generator=g).to(torch.bfloat16).cuda()
+    mask = (torch.rand(n, generator=g) > 0.5).to(torch.uint8).cuda()
+    y = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_dropout_apply', n, _lib.BF16, _lib.ptr(x), _lib.ptr(mask), 2.0, _lib.ptr(y), 0, _lib.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, (x.float() * mask.float() * 2).to(torch.bfloat16))
+    ctx.call('ifcbk_dropout_apply', n, _lib.BF16, _lib.ptr(x), None, 1.0, _lib.ptr(y), 1, _lib.cur_stream())       # eval copy, accumulating
+    torch.cuda.synchronize()
+    assert torch.equal(y, ((x.float() * mask.float() * 2).to(torch.bfloat16).float() + x.float()).to(torch.bfloat16))
+    N, H, W, Cc, ld = 3, 6, 6, 16, 24
+    t = torch.randn(N, H, W, ld, generator=g).to(torch.bfloat16).cuda()
+    flat = torch.zeros(N, Cc * H * W, dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_flatten_chw', N, H * W, Cc, _lib.BF16, _lib.ptr(t), ld, _lib.ptr(flat), 1, 0, _lib.cur_stream())
+    torch.cuda.synchronize()
+    want = torch.flatten(t[..., :Cc].permute(0, 3, 1, 2), 1)
+    assert torch.equal(flat, want)
+    back = torch.ones(N, H, W, ld, dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_flatten_chw', N, H * W, Cc, _lib.BF16, _lib.ptr(back), ld, _lib.ptr(flat), 0, 1, _lib.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(back[..., :Cc], (t[..., :Cc].float() + 1).to(torch.bfloat16))
+    assert (back[..., Cc:] == 1).all()
+
+
+def test_names_the_reference_rejects():
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    with pytest.raises(KeyError, match='model unknown!'):
+        get_namebrand_model('mobilenet_v2', 3)
+    with pytest.raises(AttributeError):
+        get_namebrand_model('vgg17', 3)             # the reference: getattr(torchvision.models, 'vgg17')
