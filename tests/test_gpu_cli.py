@@ -199,3 +199,28 @@ def test_checkpoint_layout_gobig_and_h5_preflight(tmp_path, capsys):
     except ImportError:
         with pytest.raises(SystemExit, match='h5py'):
             _cli(['--batch', '8', '--loaders', '0', 'RUN', str(tmp_path / 'run-data'), path, 'h5', '--outdir', str(tmp_path / 'run_h5')])
+
+
+@pytest.mark.parametrize('model,first_key,first_shape,head_key,head_shape',
+                         [('squeezenet', 'model.features.0.weight', (64, 3, 3, 3), 'model.classifier.1.weight', (2, 512, 1, 1)),
+                          ('alexnet', 'model.features.0.weight', (64, 3, 11, 11), 'model.classifier.6.weight', (2, 4096))])
+def test_train_then_run_other_backbone_families(tmp_path, model, first_key, first_shape, head_key, head_shape):
+    """the same CLI round trip on backbones without BatchNorm (neuston_models.py:27-33): the checkpoint carries torchvision's
+    state_dict layout with the head the reference rebuilds for the dataset's classes, and RUN reloads it"""
+    src = str(tmp_path / 'training-data')
+    os.makedirs(src)
+    _make_dataset(src, per_class=16)
+    outdir = str(tmp_path / 'training-output' / 'fam')
+    _cli(['--batch', '8', '--loaders', '0', 'TRAIN', src, model, 'fam', '--untrain', '--seed', '2', '--emax', '3', '--emin', '1',
+          '--estop', '0', '--outdir', outdir, '--learning-rate', '0.0001', '--results', 'results.json', 'output_scores'])
+    ck = torch.load(os.path.join(outdir, 'fam.ptl'), map_location='cpu', weights_only=False)
+    sd = ck['state_dict']
+    assert list(sd)[0] == first_key and tuple(sd[first_key].shape) == first_shape
+    assert tuple(sd[head_key].shape) == head_shape and ck['hyper_parameters']['resize'] == 224
+    rows = open(os.path.join(outdir, 'epochs.csv')).read().strip().splitlines()
+    assert len(rows) == 4 and all(float(r.split(',')[2]) == float(r.split(',')[2]) for r in rows[1:])       # finite losses
+    run_out = str(tmp_path / 'run-output')
+    _cli(['--batch', '8', '--loaders', '0', 'RUN', src, os.path.join(outdir, 'fam.ptl'), 'r1', '--type', 'img',
+          '--outdir', run_out + '/{RUN_ID}', '--outfile', 'img_results.json'])
+    res = json.load(open(os.path.join(run_out, 'r1', 'img_results.json')))
+    assert len(res['output_scores']) == 32 and np.allclose(np.sum(res['output_scores'], 1), 1.0, atol=1e-4)
