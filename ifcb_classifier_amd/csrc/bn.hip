@@ -456,20 +456,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx,
 }
 
 // pass 2: sum the row-tile partials (fixed order) -> dbeta, dgamma (+ temp copy used by pass 3)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int ntiles, int C, float* dgamma,
-                                                               float* dbeta, float* tmp, int accumulate, int ldp) {
-    __shared__ double s[2][16][16];
+// (1024 threads = 64 row groups x 16 channels: the 17x17 layers have 289 row tiles -- with 16 row groups a thread walked 18 of
+// them in five dependent round trips and the kernel took 11.7 us, 96 times per step)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int ntiles, int C, float* dgamma,
+                                                                float* dbeta, float* tmp, int accumulate, int ldp) {
+    __shared__ double s[2][64][16];
     const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + c;
     double a = 0.0, b = 0.0;
     if (ch < C) {
         int i = rg;
-        for (; i + 48 < ntiles; i += 64) {           // four tiles per trip: independent loads, fixed-order adds
+        for (; i + 192 < ntiles; i += 256) {         // four tiles per trip: independent loads, fixed-order adds
             float v[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[2 * u] = part[((size_t)(i + 16 * u) * 2 + 0) * ldp + ch];
-                v[2 * u + 1] = part[((size_t)(i + 16 * u) * 2 + 1) * ldp + ch];
+                v[2 * u] = part[((size_t)(i + 64 * u) * 2 + 0) * ldp + ch];
+                v[2 * u + 1] = part[((size_t)(i + 64 * u) * 2 + 1) * ldp + ch];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
                 b += (double)v[2 * u + 1];
             }
         }
-        for (; i < ntiles; i += 16) {
+        for (; i < ntiles; i += 64) {
             a += (double)part[((size_t)i * 2 + 0) * ldp + ch];
             b += (double)part[((size_t)i * 2 + 1) * ldp + ch];
         }
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
     __syncthreads();
     if (threadIdx.x < 16 && ch < C) {
         double sa = 0.0, sg = 0.0;
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 64; ++i) {
             sa += s[0][i][c];
             sg += s[1][i][c];
         }
@@ -617,7 +619,7 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 2>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
         else hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 0>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce_pool2x2");
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate, C);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate, C);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
         const float invM2 = (float)(1.0 / (double)M);
         const size_t shm2 = (size_t)5 * C * sizeof(float);
@@ -641,7 +643,7 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
     const int64_t total = M * (C / E);
     if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: tensor too large");

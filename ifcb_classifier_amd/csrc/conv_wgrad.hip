@@ -720,6 +720,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* slab, ReduceSeg
     }
 }
 
+// the same sums (identical order per output: bitwise the same result) four outputs per thread: 16-byte loads, 256 outputs per
+// block.  For tensors whose filter rows are whole float4s and unpadded (C == Cw): every layer but the 3-channel stem conv.
+// The scalar kernel moved its 34 MB per launch at 2.1 TB/s and ran 68 times per step.
+__global__ __launch_bounds__(256) void wgrad_reduce4(const float* slab, ReduceSegs sg_, int nsplit, int K, int RSC, int accumulate) {
+    __shared__ float4 part[4][64];
+    int si = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q)
+        if (q < sg_.nseg && (int)blockIdx.x >= sg_.blk0[q]) si = q;
+    float* dw = sg_.dw[si];
+    const int k_off = sg_.k_off[si], Kseg = sg_.kseg[si];
+    const int64_t total4 = (int64_t)Kseg * RSC / 4;
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t i = (int64_t)((int)blockIdx.x - sg_.blk0[si]) * 64 + o;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < total4) {
+        const float4* src = reinterpret_cast<const float4*>(slab + (int64_t)k_off * RSC) + i;
+        const int64_t stride = (int64_t)K * RSC / 4;
+        float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        int sp = sg;
+        for (; sp + 4 < nsplit; sp += 8) {
+            const float4 a = src[sp * stride], b = src[(sp + 4) * stride];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (sp < nsplit) {
+            const float4 a = src[sp * stride];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        s = float4{s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+    }
+    part[sg][o] = s;
+    __syncthreads();
+    if (sg == 0 && i < total4) {
+        const float4 p0 = part[0][o], p1 = part[1][o], p2 = part[2][o], p3 = part[3][o];
+        float4 r = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                    (p0.w + p1.w) + (p2.w + p3.w)};
+        float4* dst = reinterpret_cast<float4*>(dw) + i;
+        if (accumulate) {
+            const float4 d0 = *dst;
+            r.x += d0.x; r.y += d0.y; r.z += d0.z; r.w += d0.w;
+        }
+        *dst = r;
+    }
+}
+
 int pick_mt(int K, int maxmt) {
     int best = 1;
     long bestc = -1;
@@ -884,6 +930,10 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_bf16");
     ReduceSegs rs;
     rs.nseg = nseg;
+    const int RSCw = d->R * d->S * d->Cw;
+    bool vec4 = d->C == d->Cw && RSCw % 4 == 0;
+    for (int sgi = 0; sgi < nseg; ++sgi) vec4 = vec4 && ((uintptr_t)dws[sgi] % 16 == 0);
+    const int per_blk = vec4 ? 256 : 64;
     int k_off = 0, blk = 0;
     for (int sgi = 0; sgi < 8; ++sgi) {
         const bool live = sgi < nseg;
@@ -892,13 +942,16 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
         rs.kseg[sgi] = live ? kseg[sgi] : 0;
         rs.blk0[sgi] = blk;
         if (live) {
-            blk += cdiv((int64_t)kseg[sgi] * d->R * d->S * d->Cw, 64);
+            blk += cdiv((int64_t)kseg[sgi] * RSCw, per_blk);
             k_off += kseg[sgi];
         }
     }
     rs.blk0[8] = blk;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(blk), dim3(256), 0, st, (const float*)ctx->ws, rs, p.nsplit, d->K, d->R * d->S, d->C,
-                       d->Cw, accumulate);
+    if (vec4)
+        hipLaunchKernelGGL(wgrad_reduce4, dim3(blk), dim3(256), 0, st, (const float*)ctx->ws, rs, p.nsplit, d->K, RSCw, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce, dim3(blk), dim3(256), 0, st, (const float*)ctx->ws, rs, p.nsplit, d->K, d->R * d->S, d->C,
+                           d->Cw, accumulate);
     IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce");
     return 0;
 }
