@@ -271,6 +271,23 @@ __global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
 //                      filter pieces of K-tile T+1 (PM0/2 + TN pieces per wave); then vmcnt(PM0/2 + TN): the odd slot of T is in
 //   phase 2T+1 (odd):  reads pixel tiles [PM0, MT); issues the ODD pixel slot of K-tile T+1 (PM1/2 pieces); then vmcnt(PM1/2)
 // Slots are double-buffered by K-tile parity; every slot is re-filled two phases after its last read (WAR rule of conv_big).
+// timing experiment (built with `make EXTRA=-DIFCBK_EXPERIMENT_FRAG_AFFINE`, run with IFCBK_DEBUG_DROP=f; wrong results): what BatchNorm-apply + ReLU on the pixel fragment AFTER its LDS read
+// would cost -- the producer's activation never written, the consumer normalises what it multiplies.
+// Optimistic: scale / shift are lane constants here; a real version adds two LDS reads per fragment for the per-channel pair
+// and a border mask for padded taps.
+__device__ __forceinline__ bf16x8_t dbg_affine_relu(bf16x8_t v, float sc, float sh) {
+    u32x4_t u = __builtin_bit_cast(u32x4_t, v);
+    u32x4_t r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+        lo = fmaxf(fmaf(lo, sc, sh), 0.f);
+        hi = fmaxf(fmaf(hi, sc, sh), 0.f);
+        r[j] = pack2bf(lo, hi);
+    }
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
 template <int TN, int MT, int PM0, int MODE>
 __global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
     typedef bf16_t T;
@@ -413,6 +430,9 @@ __global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
     bf16x8_t fb[TN][2];
     bf16x8_t fa[PMX][2];
     const bool dbg_nomfma = a.dbg & 1, dbg_noread = a.dbg & 2, dbg_nodma = a.dbg & 4;
+#ifdef IFCBK_EXPERIMENT_FRAG_AFFINE
+    const float dbg_sc = 1.0f + 1e-3f * (float)(lane & 7), dbg_sh = 1e-3f * (float)(lane >> 3);
+#endif
 #pragma unroll
     for (int i = 0; i < TN; ++i) fb[i][0] = fb[i][1] = bf16x8_t{};
 #pragma unroll
@@ -452,6 +472,15 @@ __global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
             for (int nt = 0; nt < TN; ++nt) asm volatile("" : "+v"(fb[nt][0]), "+v"(fb[nt][1]));
 #pragma unroll
             for (int ml = 0; ml < PM0; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
+#ifdef IFCBK_EXPERIMENT_FRAG_AFFINE
+            if (a.dbg & 16) {
+#pragma unroll
+                for (int ml = 0; ml < PM0; ++ml) {
+                    fa[ml][0] = dbg_affine_relu(fa[ml][0], dbg_sc, dbg_sh);
+                    fa[ml][1] = dbg_affine_relu(fa[ml][1], dbg_sc, dbg_sh);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             if (!dbg_nomfma)
@@ -490,6 +519,15 @@ __global__ __launch_bounds__(512) void conv_pp2(ConvArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ml = 0; ml < PM1; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
+#ifdef IFCBK_EXPERIMENT_FRAG_AFFINE
+            if (a.dbg & 16) {
+#pragma unroll
+                for (int ml = 0; ml < PM1; ++ml) {
+                    fa[ml][0] = dbg_affine_relu(fa[ml][0], dbg_sc, dbg_sh);
+                    fa[ml][1] = dbg_affine_relu(fa[ml][1], dbg_sc, dbg_sh);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             if (!dbg_nomfma)
@@ -611,6 +649,7 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_
         if (strchr(e, 'r')) a.dbg |= 2;           // no fragment reads
         if (strchr(e, 'd')) a.dbg |= 4;           // no LDS-DMA pieces
         if (strchr(e, 'e')) a.dbg |= 8;           // no epilogue
+        if (strchr(e, 'f')) a.dbg |= 16;          // affine + ReLU on every pixel fragment after its LDS read
     }
     if (mt == 8 && tn == 2) launch_big<2, 8>(a, st);
     else if (mt == 8 && tn == 3) launch_big<3, 8>(a, st);

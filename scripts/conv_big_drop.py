@@ -16,7 +16,7 @@ for name, (N, Cc, H, W, K, R, S, sh, sw, ph, pw) in L.items():
     flops = 2.0 * N * P * Q * K * R * S * Cc
     os.environ['IFCBK_CONV_BIG'] = '2'
     res = []
-    for drop in ('', 'e', 'mrd', 'mrde', 'rd', 'rde', 'm', 'me'):
+    for drop in (sys.argv[1].split(',') if len(sys.argv) > 1 else ('', 'e', 'mrd', 'mrde', 'rd', 'rde', 'm', 'me')):
         os.environ['IFCBK_DEBUG_DROP'] = drop
         run = lambda: ctx.call('ifcbk_conv2d_fwd', C.byref(d), _lib.ptr(x), _lib.ptr(w), _lib.ptr(y), _lib.ptr(part), st)
         run(); torch.cuda.synchronize()
@@ -27,5 +27,5 @@ for name, (N, Cc, H, W, K, R, S, sh, sw, ph, pw) in L.items():
             for _ in range(3): run()
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 3)
-        res.append('%s %.1f us' % (drop or 'full', best * 1e3))
+        res.append('%s %.1f us' % (drop if drop not in ('', 'x') else 'full', best * 1e3))
     print(name, ' | '.join(res), '| full = %.0f TF/s' % (flops / float(res[0].split()[1]) / 1e6), flush=True)
