@@ -239,17 +239,32 @@ __device__ __forceinline__ void pooled_dy_2x2(const PoolGather& g, const T* dp, 
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < E; ++j) fd[k][j] = 0.f;
+    // all eight loads are issued before the first is used: windows outside the pooled map read a clamped address and are
+    // switched off by data (arg-max 255 matches no tap).  With the loads inside `if (inside) { load; use }` bodies every window
+    // cost its own memory round trip and these kernels ran at 3.2-3.8 TB/s, latency-bound
+    typename Chunk<T>::raw_t rf[4];
+    int idx[4][E];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int p = hb - 1 + u, q = wb - 1 + v;
-            if (p < 0 || p >= g.P || q < 0 || q >= g.Q) continue;
-            const int64_t opix = (int64_t)(n * g.P + p) * g.Q + q;
-            int idx[E];
+            const bool in = p >= 0 && p < g.P && q >= 0 && q < g.Q;
+            const int pc = p < 0 ? 0 : (p >= g.P ? g.P - 1 : p), qc = q < 0 ? 0 : (q >= g.Q ? g.Q - 1 : q);
+            const int64_t opix = (int64_t)(n * g.P + pc) * g.Q + qc;
+            ArgPack<E>::load(g.arg + opix * g.C + c, idx[u * 2 + v]);
+            rf[u * 2 + v] = Chunk<T>::load_raw(dp + opix * g.ldp + c);
+            if (!in) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) idx[u * 2 + v][j] = 255;
+            }
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
             float f[E];
-            ArgPack<E>::load(g.arg + opix * g.C + c, idx);
-            Chunk<T>::load(dp + opix * g.ldp + c, f);
+            Chunk<T>::widen(rf[u * 2 + v], f);
             // window (u,v) holds pixel (a,b) of the block at tap (a + 2(1-u), b + 2(1-v)) when that is < 3
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -260,7 +275,7 @@ __device__ __forceinline__ void pooled_dy_2x2(const PoolGather& g, const T* dp, 
                     const int want = r * 3 + sx;
 #pragma unroll
                     for (int j = 0; j < E; ++j)
-                        if (idx[j] == want) fd[a * 2 + b][j] += f[j];
+                        if (idx[u * 2 + v][j] == want) fd[a * 2 + b][j] += f[j];
                 }
         }
 }
@@ -296,17 +311,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool2x2_kernel(const T* x, 
             const uint32_t rem = b - n * fHBWB.d;
             const int hb = (int)fdiv(rem, fWB);
             const int wb = (int)rem - hb * WB;
+            typename Chunk<T>::raw_t rx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // (a block on the odd last row / column re-reads its neighbour; masked below)
+                const int h = min(2 * hb + (k >> 1), pg.H - 1), w = min(2 * wb + (k & 1), pg.W - 1);
+                rx[k] = Chunk<T>::load_raw(x + ((int64_t)(n * pg.H + h) * pg.W + w) * ldx + c);
+            }
             float fd[4][E];
             pooled_dy_2x2<T>(pg, dp, n, hb, wb, c, fd);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int h = 2 * hb + (k >> 1), w = 2 * wb + (k & 1);
-                if (h >= pg.H || w >= pg.W) continue;
+                const bool in = 2 * hb + (k >> 1) < pg.H && 2 * wb + (k & 1) < pg.W;
                 float fx[E];
-                Chunk<T>::load(x + ((int64_t)(n * pg.H + h) * pg.W + w) * ldx + c, fx);
+                Chunk<T>::widen(rx[k], fx);
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
-                    float dz = fd[k][j];
+                    float dz = in ? fd[k][j] : 0.f;
                     if (MASK == 2) dz = (fx[j] * sc[j] + sh[j]) > 0.f ? dz : 0.f;
                     sb[j] += dz;
                     sg[j] += dz * ((fx[j] - mu[j]) * is[j]);
@@ -366,6 +386,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_pool2x2_kernel(const T* x, int 
     const uint32_t rem = b - n * fHBWB.d;
     const int hb = (int)fdiv(rem, fWB);
     const int wb = (int)rem - hb * WB;
+    typename Chunk<T>::raw_t rx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = min(2 * hb + (k >> 1), pg.H - 1), w = min(2 * wb + (k & 1), pg.W - 1);
+        rx[k] = Chunk<T>::load_raw(x + ((int64_t)(n * pg.H + h) * pg.W + w) * ldx + c);
+    }
     float fd[4][E];
     pooled_dy_2x2<T>(pg, dp, n, hb, wb, c, fd);
 #pragma unroll
@@ -374,7 +400,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_pool2x2_kernel(const T* x, int 
         if (h >= pg.H || w >= pg.W) continue;
         const int64_t pix = (int64_t)(n * pg.H + h) * pg.W + w;
         float fx[E], o[E];
-        Chunk<T>::load(x + pix * ldx + c, fx);
+        Chunk<T>::widen(rx[k], fx);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             float dz = fd[k][j];
@@ -771,27 +797,34 @@ __global__ __launch_bounds__(256) void bn_apply_maxpool_kernel(const T* x, const
     int bi[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) { sc[j] = coef[c + j]; sf[j] = coef[C + c + j]; best[j] = -INFINITY; bi[j] = 0; }
-    bool first = true;
+    // the nine taps are requested before the first is used (clamped addresses; taps in the padding are switched off by data):
+    // with `if (inside) { load; compare }` bodies every tap was its own memory round trip (3.5 TB/s)
+    typename Chunk<T>::raw_t rv[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int h = h0 + r;
-        if (h < 0 || h >= a.H) continue;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const int w = w0 + s;
-            if (w < 0 || w >= a.W) continue;
+            const int h = min(max(h0 + r, 0), a.H - 1), w = min(max(w0 + s, 0), a.W - 1);
+            rv[r * 3 + s] = Chunk<T>::load_raw(x + ((int64_t)(n * a.H + h) * a.W + w) * a.ldx + c);
+        }
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int h = h0 + r, w = w0 + s;
+            const bool in = h >= 0 && h < a.H && w >= 0 && w < a.W;
             float f[E];
-            Chunk<T>::load(x + ((int64_t)(n * a.H + h) * a.W + w) * a.ldx + c, f);
+            Chunk<T>::widen(rv[r * 3 + s], f);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 float v = f[j] * sc[j] + sf[j];
                 if (a.relu) v = fmaxf(v, 0.f);
                 v = Chunk<T>::round(v);
-                if (first || v > best[j] || v != v) { best[j] = v; bi[j] = r * 3 + s; }
+                if (in && (first || v > best[j] || v != v)) { best[j] = v; bi[j] = r * 3 + s; }
             }
-            first = false;
+            first = first && !in;
         }
-    }
     Chunk<T>::store(y + (int64_t)pix * a.ldy + c, best);
     if (arg) ArgPack<E>::store(arg + (int64_t)pix * C + c, bi);
 }
