@@ -500,12 +500,15 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(const float* dl, const fl
     for (int n = 0; n < N; ++n) s += dl[(size_t)n * NC + j] * feat[(size_t)n * C + c];      // 8 independent loads in flight, one fixed sum order
     dW[i] = accumulate ? dW[i] + s : s;
 }
-__global__ void fc_bgrad_kernel(const float* dl, float* db, int N, int NC, int accumulate) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= NC) return;
+// one wave per class: lane-strided partial sums over the batch, then a fixed butterfly (a thread per class walking all N samples
+// alone took 62 us at batch 256 -- at the one point of a step where nothing else can run: between the loss and the backward)
+__global__ __launch_bounds__(64) void fc_bgrad_kernel(const float* dl, float* db, int N, int NC, int accumulate) {
+    const int j = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dl[(size_t)n * NC + j];
-    db[j] = accumulate ? db[j] + s : s;
+    for (int n = lane; n < N; n += 64) s += dl[(size_t)n * NC + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) db[j] = accumulate ? db[j] + s : s;
 }
 // dx[n,hw,c] = (sum_j dl[n][j] W[j][c]) * mask*scale / HW ; thread per (n, 16-byte chunk of channels)
 template <class T>
@@ -793,7 +796,7 @@ extern "C" int ifcbk_head_bwd(ifcbk_ctx* ctx, const ifcbk_head_desc* d, const fl
     if (W) {
         hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((int64_t)d->NC * d->C, 256)), dim3(256), 0, ST, dlogits, feat, dW, d->N, d->C, d->NC, param_accumulate);
         IFCBK_LAUNCH_CHECK(ctx, "fc_wgrad");
-        hipLaunchKernelGGL(fc_bgrad_kernel, dim3(cdiv(d->NC, 64)), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
+        hipLaunchKernelGGL(fc_bgrad_kernel, dim3(d->NC), dim3(64), 0, ST, dlogits, db, d->N, d->NC, param_accumulate);
         IFCBK_LAUNCH_CHECK(ctx, "fc_bgrad");
     }
     if (dx) {
