@@ -122,12 +122,21 @@ def run_mode_leg(args, local):
         nb = (n_rois + B - 1) // B
         pl = eng.plan(B)
 
-        def batch(k):
+        def stage(k):
             s0 = (k * B) % POOL
-            eng.load_rois(rois['pixels'], rois['offs'][s0:s0 + B], rois['hs'][s0:s0 + B], rois['ws'][s0:s0 + B], rois['max_h'],
-                          rois['max_w'])
-            eng.forward_eval(B)
-            eng.run(pl.softmax)
+            slot, side = eng.prefetch_begin()
+            with torch.cuda.stream(side):
+                eng.load_rois(rois['pixels'], rois['offs'][s0:s0 + B], rois['hs'][s0:s0 + B], rois['ws'][s0:s0 + B], rois['max_h'],
+                              rois['max_w'], slot=slot)
+            eng.prefetch_end(slot)
+
+        def batch(k):
+            # batch k was staged by the previous call; batch k+1 is preprocessed on the side stream beside this forward
+            eng.use_prefetched()
+            stage(k + 1)
+            p = eng.forward_eval(B)
+            eng.run(p.softmax)
+        stage(0)
         for k in range(3):
             batch(k)
         torch.cuda.synchronize()
@@ -238,12 +247,36 @@ def main():
     def allred(t):
         return dist.all_reduce(t, async_op=True)
 
-    def step(k=None, ev_arr=None):
-        eng.load_rois(**rois)
+    # input pipelining (the product's Trainer does the same, neuston_net.Trainer._lookahead): the on-GPU preprocessing of batch
+    # k+1 runs on a side stream into the engine's other input slot while step k computes.  Every timed step still contains
+    # exactly one preprocess and one train step.  Default OFF here: with the inputs already in HBM there is no upload to hide and
+    # a fifth stream next to the four program lanes costs 0.5 ms per step on this runtime (4 hardware queues per process;
+    # GPU_MAX_HW_QUEUES=8 is far worse) -- measured 24.40 vs 23.92 ms.  What it buys is in `pcie_inclusive` below.
+    pipelined = os.environ.get('IFCBK_BENCH_PIPELINE', '0') != '0'
+    for tb in eng.tgt_bufs:
+        tb[:B].copy_(eng.tgt_bufs[0][:B])
+
+    def stage():
+        slot, side = eng.prefetch_begin()
+        with torch.cuda.stream(side):
+            eng.load_rois(slot=slot, **rois)
+        eng.prefetch_end(slot)
+
+    stage_first = os.environ.get('IFCBK_BENCH_STAGE_FIRST', '0') != '0'
+
+    def step(k=None, ev_arrs=None):
+        if pipelined:
+            eng.use_prefetched()
+            if stage_first:
+                stage()
+        else:
+            eng.load_rois(**rois)
         if world > 1:
             eng.train_step_ddp(B, world, allred)
         else:
-            eng.train_step(B, ev_slot=k, ev_arr=ev_arr)
+            eng.train_step(B, ev_slot=k, ev_arr=None if ev_arrs is None else ev_arrs[eng.in_slot])
+        if pipelined and not stage_first:
+            stage()          # enqueued behind the step's ~800 launches: reaches the GPU while the backward pass runs
 
     def op_table(nsteps):
         """per-kernel sums of the event-bracketed ops of event slots 0..nsteps-1"""
@@ -273,6 +306,8 @@ def main():
         eng.ctx.lib.ifcbk_op_kernel(C.byref(pl.step.arr[j]), nm, 64)
         return nm.value.decode() or _lib.OP_NAMES[pl.step.arr[j].kind]
 
+    if pipelined:
+        stage()
     for _ in range(args.warmup):
         step()
     # untimed survey pass: every op bracketed by HIP events, all ops back to back on ONE lane -> the per-kernel table
@@ -281,7 +316,7 @@ def main():
     survey, ev_dom, dom = None, None, None
     if do_survey:
         NS = 3
-        ev_all = pl.step.timed(single_lane=True)
+        ev_all = eng.plan(B).step.timed(single_lane=True)     # (the plan of the input slot the warm-up left current)
         for k in range(NS):
             eng.load_rois(**rois)
             eng.train_step(B, ev_slot=k, ev_arr=ev_all)      # N>1: three LOCAL steps (no all-reduce) ...
@@ -295,7 +330,13 @@ def main():
         # dominant kernel = the conv kernel instantiation (the name rocprofv3 lists) with the most time per step
         dom = max(conv, key=lambda k: conv[k]['ms'])
         if use_ev:
-            ev_dom = pl.step.timed([j for j in range(pl.step.n) if kernel_of(j) == dom])
+            domops = [j for j in range(pl.step.n) if kernel_of(j) == dom]
+            cur = eng.in_slot
+            ev_dom = {}
+            for sl in (0, 1):                                 # one event-flagged op table per input slot
+                eng._select_slot(sl)
+                ev_dom[sl] = eng.plan(B).step.timed(domops)
+            eng._select_slot(cur)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -317,9 +358,16 @@ def main():
     # secondary number (BASELINE metric is "train + infer"): RUN-mode inference on the same ROIs -- on-GPU
     # preprocess -> eval forward (BN from running statistics) -> softmax; replicas only, no collective
     def infer_step():
-        eng.load_rois(**rois)
+        if pipelined:
+            eng.use_prefetched()
+            if stage_first:
+                stage()
+        else:
+            eng.load_rois(**rois)
         p = eng.forward_eval(B)
         eng.run(p.softmax)
+        if pipelined and not stage_first:
+            stage()
 
     n_inf = 0 if args.train_only else args.steps
     for _ in range(2 if n_inf else 0):
@@ -339,6 +387,44 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dti = float(tt.item())
 
+    # PCIe-inclusive rate (the boundary as the product's DataLoader feeds it: a pinned host batch per step -- one ragged u8 blob
+    # plus offset / size tables, <= 23 MB): upload -> on-GPU preprocess -> train step, on one stream and with one batch of
+    # look-ahead on the side stream (neuston_net.Trainer's loop).  Never the headline `value`.
+    pcie = None
+    if world == 1 and not args.train_only:
+        hostb = {k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in rois.items()}
+        up = lambda: {k: (v.to(eng.dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in hostb.items()}
+
+        def one_stream():
+            eng.load_rois(**up())
+            eng.train_step(B)
+
+        def stage_host():
+            slot, side = eng.prefetch_begin()
+            with torch.cuda.stream(side):
+                eng.load_rois(slot=slot, **up())
+            eng.prefetch_end(slot)
+
+        def looked_ahead():
+            eng.use_prefetched()
+            stage_host()
+            eng.train_step(B)
+
+        pcie = {}
+        for name, fn, pre in (('one_stream', one_stream, None), ('look_ahead', looked_ahead, stage_host)):
+            if pre:
+                pre()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            pcie[name + '_ms_per_step'] = round(1e2 * (time.perf_counter() - tp), 3)
+        pcie['upload_mb_per_step'] = round(sum(v.numel() * v.element_size() for v in hostb.values() if torch.is_tensor(v)) / 1e6, 2)
+        pcie['note'] = 'train step fed from a pinned host batch every step (10 timed steps each); look_ahead = the product Trainer loop'
+
     out = None
     if rank == 0:
         ips = world * B * args.steps / dt
@@ -349,11 +435,15 @@ def main():
             'config': {'workload': 'inception_v3 100-class bf16 TRAIN, batch %d per GPU, synthetic u8 ROIs h,w~U{32..299} '
                                    'resized on-GPU to 299x299 (BASELINE.json configs[1])' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'program_lanes': eng.NL, 'optimizer': 'adam lr=1e-3',
-                       'loss': 'CE + 0.4*CE_aux'},
+                       'loss': 'CE + 0.4*CE_aux',
+                       'input_pipeline': ('preprocess of batch k+1 on a side stream beside step k (two input slots); one preprocess + '
+                                          'one train step per timed step') if pipelined else 'preprocess then step on one stream'},
             'train_tflops': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3, 2),
             'mfma_frac_whole_step': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
             'final_loss': round(loss, 4),
         }
+        if pcie:
+            out['pcie_inclusive'] = pcie
         if n_inf:
             out.update({'infer_images_per_s': round(world * B * n_inf / dti, 1),
                         'infer_ms_per_batch': round(1e3 * dti / n_inf, 3),

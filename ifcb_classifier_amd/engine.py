@@ -478,7 +478,14 @@ class Engine:
         for n in self.drops:
             n.mask = torch.ones(N, n.x.H * n.x.W * n.x.C, dtype=torch.uint8, device=dev)
         self.probs = torch.zeros(N, net.NC, dtype=torch.float32, device=dev)
-        self.target = torch.zeros(N, dtype=torch.int64, device=dev)
+        # Two input slots (network input tensor + labels): while a step runs on slot s, the next batch is uploaded and
+        # preprocessed into slot 1-s on a side stream (prefetch_begin / prefetch_end / use_prefetched).  Programs are built per
+        # slot (only the pointers of the first conv, its weight gradient and the loss ops differ).
+        self.tgt_bufs = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.in_bufs = [self.act[net.input.id], torch.zeros_like(self.act[net.input.id])]
+        self.in_slot = 0
+        self.pre_stream = self.pre_ctx = None
+        self.ev_ready, self.ev_free, self.prefetched = [None, None], [None, None], None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
         # workspace: wgrad split-K slabs / bn_bwd partials
@@ -497,6 +504,50 @@ class Engine:
             M = N * n.x.H * n.x.W
             ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         self.ctx.reserve(ws)
+
+    @property
+    def target(self):
+        return self.tgt_bufs[self.in_slot]
+
+    # ------------------------------------------------------------------ input pipelining
+    def _select_slot(self, slot):
+        self.in_slot = slot
+        self.act[self.net.input.id] = self.in_bufs[slot]
+
+    def prefetch_begin(self):
+        """-> (slot, stream): everything the caller enqueues on `stream` until prefetch_end() -- host-to-device copies of the
+        next batch, load_rois(..., slot=slot), the label copy into tgt_bufs[slot] -- runs beside the step in flight.  The side
+        stream first waits until the last step that read this slot has finished."""
+        if self.plan_only:
+            raise RuntimeError('prefetch: this engine was built with plan_only=True')
+        if self.pre_stream is None:
+            self.pre_stream = torch.cuda.Stream(self.dev)
+            self.pre_ctx = _lib.Context(self.dev.index)          # its own workspace arena: the resize tables of the prefetch
+        slot = 1 - self.in_slot
+        if self.ev_free[slot] is not None:
+            self.pre_stream.wait_event(self.ev_free[slot])
+        return slot, self.pre_stream
+
+    def prefetch_end(self, slot):
+        ev = torch.cuda.Event()
+        ev.record(self.pre_stream)
+        self.ev_ready[slot] = ev
+        self.prefetched = slot
+
+    def use_prefetched(self):
+        """make the prefetched slot the current one: the caller's stream waits for its preprocessing; the slot just left is
+        marked busy until everything enqueued so far (the step that read it) has finished."""
+        slot = self.prefetched
+        if slot is None:
+            raise RuntimeError('use_prefetched: nothing was prefetched')
+        cur = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.ev_free[self.in_slot] = ev
+        cur.wait_event(self.ev_ready[slot])
+        self._select_slot(slot)
+        self.prefetched = None
+        return slot
 
     def activation_bytes(self):
         tot = sum(t.numel() * t.element_size() for t in self.act.values())
@@ -591,9 +642,10 @@ class Engine:
     def plan(self, N):
         if N > self.max_batch:
             raise RuntimeError('batch %d exceeds the engine capacity %d' % (N, self.max_batch))
-        if N not in self._plans:
-            self._plans[N] = self._build(N)
-        return self._plans[N]
+        key = (N, self.in_slot)
+        if key not in self._plans:
+            self._plans[key] = self._build(N)
+        return self._plans[key]
 
     def _build(self, N):
         net = self.net
@@ -1263,8 +1315,16 @@ class Engine:
                       self.stream())
         return N
 
-    def load_rois(self, pixels, offs, hs, ws, max_h, max_w, in_channels=1, flips=None, mean=None, std=None):
-        """ragged u8 ROIs (device tensors) -> input buffer via the PIL-exact resize kernel."""
+    def load_rois(self, pixels, offs, hs, ws, max_h, max_w, in_channels=1, flips=None, mean=None, std=None, slot=None):
+        """ragged u8 ROIs (device tensors) -> input buffer via the PIL-exact resize kernel.  slot: the input slot of a
+        prefetch (runs on the prefetch stream with the prefetch context's workspace); None = the current slot, current stream."""
+        if slot is not None:
+            return self._load_rois_into(self.pre_ctx, C.c_void_p(self.pre_stream.cuda_stream), self.in_bufs[slot], False,
+                                        pixels, offs, hs, ws, max_h, max_w, in_channels, flips, mean, std)
+        return self._load_rois_into(self.ctx, self.stream(), self.act[self.net.input.id], True, pixels, offs, hs, ws, max_h,
+                                    max_w, in_channels, flips, mean, std)
+
+    def _load_rois_into(self, ctx, stream, dst, main, pixels, offs, hs, ws, max_h, max_w, in_channels, flips, mean, std):
         n = hs.numel()
         d = RoiDesc()
         d.n_img, d.S, d.in_channels, d.out_channels = n, self.net.S, in_channels, 8
@@ -1277,15 +1337,18 @@ class Engine:
         if self.net.transform_input:
             for k, (s, m) in enumerate(((0.229, 0.485), (0.224, 0.456), (0.225, 0.406))):
                 d.tin_scale[k], d.tin_shift[k] = s / 0.5, (m - 0.5) / 0.5
-        need = self.ctx.lib.ifcbk_roi_preprocess_workspace(C.byref(d), int(max_h), int(max_w))
-        if need > self.ctx.lib.ifcbk_ctx_workspace_bytes(self.ctx.h):
-            self.ctx.reserve(need)
-            for pl in self._plans.values():          # the workspace moved: graphs captured so far hold stale pointers
-                for g in pl.graphs.values():
-                    self.ctx.lib.ifcbk_graph_destroy(self.ctx.h, g)
-                pl.graphs.clear()
-        self.ctx.call('ifcbk_roi_preprocess', C.byref(d), _vp(pixels), _vp(offs), _vp(hs), _vp(ws), _vp(flips),
-                      int(max_h), int(max_w), _vp(self.act[self.net.input.id]), None, self.stream())
+        need = ctx.lib.ifcbk_roi_preprocess_workspace(C.byref(d), int(max_h), int(max_w))
+        if need > ctx.lib.ifcbk_ctx_workspace_bytes(ctx.h):
+            if not main:
+                self.pre_stream.synchronize()        # an earlier prefetch may still read the arena that is about to move
+            ctx.reserve(need)
+            if main:
+                for pl in self._plans.values():          # the workspace moved: graphs captured so far hold stale pointers
+                    for g in pl.graphs.values():
+                        self.ctx.lib.ifcbk_graph_destroy(self.ctx.h, g)
+                    pl.graphs.clear()
+        ctx.call('ifcbk_roi_preprocess', C.byref(d), _vp(pixels), _vp(offs), _vp(hs), _vp(ws), _vp(flips),
+                 int(max_h), int(max_w), _vp(dst), None, stream)
         return n
 
     def make_dropout_mask(self, N):

@@ -297,6 +297,44 @@ class NeustonModel(nn.Module):
         eng.train_step(N)
         return N
 
+    # ---- pipelined form of the three batch calls: the NEXT batch is uploaded and preprocessed on a side stream into the
+    # engine's other input slot while the current step runs (Engine.prefetch_begin / prefetch_end / use_prefetched):
+    #     n = model.stage_batch(first);  for each batch: model.use_staged(); n2 = model.stage_batch(next); model.fit_current(n)
+    def stage_batch(self, rois, transform=None, input_classes=None):
+        from .neuston_data import rois_to_device
+        eng = self.model.engine
+        slot, side = eng.prefetch_begin()
+        with torch.cuda.stream(side):
+            kw = rois_to_device(rois, eng.dev, transform)
+            n = eng.load_rois(slot=slot, **kw)
+            if input_classes is not None:
+                eng.tgt_bufs[slot][:n].copy_(input_classes, non_blocking=True)
+        eng.prefetch_end(slot)
+        return n
+
+    def use_staged(self):
+        self.model.engine.use_prefetched()
+
+    def fit_current(self, N, world=1, all_reduce=None):
+        eng = self.model.engine
+        self.model.train()
+        if world > 1:
+            eng.train_step_ddp(N, world, all_reduce)
+        else:
+            eng.train_step(N)
+        return N
+
+    def eval_current(self, N, with_loss=False):
+        eng = self.model.engine
+        self.model.eval()
+        pl = eng.forward_eval(N)
+        loss = None
+        if with_loss:
+            eng.run(pl.eval_loss)
+            loss = eng.loss[0].clone()
+        eng.run(pl.softmax)
+        return eng.probs[:N].clone(), loss
+
     def fit_batch_ddp(self, input_data, input_classes, world, all_reduce):
         """data-parallel twin of fit_batch: per-rank local BatchNorm statistics (no SyncBN upstream), gradient
         all-reduce over RCCL launched per finished bucket and overlapped with the rest of backward."""

@@ -95,6 +95,16 @@ class Trainer:
         self.best_model_path = None
         self.dist, self.rank, self.world = _dist()
 
+    @staticmethod
+    def _lookahead(loader):
+        """(batch, next batch or None) pairs: the next batch is staged on the GPU's side stream while the current one runs"""
+        it = iter(loader)
+        cur = next(it, None)
+        while cur is not None:
+            nxt = next(it, None)
+            yield cur, nxt
+            cur = nxt
+
     def _allreduce(self, t):
         return self.dist.all_reduce(t, async_op=True)
 
@@ -111,19 +121,23 @@ class Trainer:
             model.current_epoch = epoch
             train_loader.set_epoch(epoch)
             ttf, vtf = train_loader.dataset.transforms, val_loader.dataset.transforms
-            for rois, targets, paths in train_loader:
-                kw = rois_to_device(rois, dev, ttf)
-                if self.world > 1:
-                    model.fit_batch_ddp(kw, targets, self.world, self._allreduce)
-                else:
-                    model.fit_batch(kw, targets)
+            # one batch of look-ahead: upload + on-GPU preprocessing of batch k+1 run on a side stream beside step k
+            n_next = None
+            for (rois, targets, paths), nxt in self._lookahead(train_loader):
+                n = model.stage_batch(rois, ttf, targets) if n_next is None else n_next
+                model.use_staged()
+                n_next = model.stage_batch(nxt[0], ttf, nxt[1]) if nxt is not None else None
+                model.fit_current(n, self.world, self._allreduce if self.world > 1 else None)
                 global_step += 1
             model.agg_train_loss = model.epoch_train_loss()
             steps = []
-            for rois, targets, paths in val_loader:
-                kw = rois_to_device(rois, dev, vtf)
+            n_next = None
+            for (rois, targets, paths), nxt in self._lookahead(val_loader):
+                n = model.stage_batch(rois, vtf, targets) if n_next is None else n_next
+                model.use_staged()
+                n_next = model.stage_batch(nxt[0], vtf, nxt[1]) if nxt is not None else None
+                probs, loss = model.eval_current(n, with_loss=True)
                 tg = targets.to(dev, non_blocking=True)
-                probs, loss = model.eval_batch(kw, tg)
                 steps.append(dict(val_batch_loss=loss, val_outputs=probs, val_input_classes=tg, val_input_srcs=list(paths)))
             steps = self._gather_val(steps, len(val_loader.dataset))
             stop = False
@@ -180,8 +194,12 @@ class Trainer:
     def test(self, model, loader, input_obj, transform, callbacks):
         dev = model.model.engine.dev
         steps = []
-        for rois, ids in loader:
-            probs, _ = model.eval_batch(rois_to_device(rois, dev, transform))
+        n_next = None
+        for (rois, ids), nxt in self._lookahead(loader):
+            n = model.stage_batch(rois, transform) if n_next is None else n_next
+            model.use_staged()
+            n_next = model.stage_batch(nxt[0], transform) if nxt is not None else None
+            probs, _ = model.eval_current(n)
             steps.append(dict(test_outputs=probs, test_srcs=list(ids)))
         rr = model.test_epoch_end(steps, input_obj)
         rr.type = 'Bin' if hasattr(input_obj, 'yearday') else 'ImgDir'
@@ -197,8 +215,12 @@ class Trainer:
         cat = torch.utils.data.ConcatDataset([ds for _, ds in bins])
         loader = DataLoader(cat, batch_size=batch_size, pin_memory=True, num_workers=num_workers, collate_fn=collate_rois)
         probs, ids = [], []
-        for rois, pids in loader:
-            p, _ = model.eval_batch(rois_to_device(rois, dev, bins[0][1].transform))
+        tf, n_next = bins[0][1].transform, None
+        for (rois, pids), nxt in self._lookahead(loader):
+            n = model.stage_batch(rois, tf) if n_next is None else n_next
+            model.use_staged()
+            n_next = model.stage_batch(nxt[0], tf) if nxt is not None else None
+            p, _ = model.eval_current(n)
             probs.append(p)
             ids.extend(pids)
         probs = torch.cat(probs, 0).detach().cpu().numpy()

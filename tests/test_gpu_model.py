@@ -370,3 +370,60 @@ def test_lane_count_does_not_change_the_result(monkeypatch):
         del eng
     for r in results[1:]:
         assert torch.equal(results[0][0], r[0]) and torch.equal(results[0][1], r[1]) and torch.equal(results[0][2], r[2])
+
+
+@pytest.mark.gpu
+def test_prefetched_input_slots_equal_sequential_steps():
+    """input pipelining (Engine.prefetch_begin / prefetch_end / use_prefetched, two input slots, preprocess of batch k+1 on a side
+    stream beside step k): four training steps and an eval forward give bitwise the parameters, running statistics, loss and
+    probabilities of the one-stream preprocess-then-step loop (reference: the DataLoader / Trainer loop, neuston_net.py:101-115)."""
+    import numpy as np
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    B, NCLS = 6, 4
+    rng = np.random.default_rng(7)
+    batches = []
+    for _ in range(5):
+        hs = rng.integers(20, 150, B).astype(np.int32)
+        ws = rng.integers(20, 150, B).astype(np.int32)
+        sizes = hs.astype(np.int64) * ws
+        offs = np.zeros(B, np.int64)
+        offs[1:] = np.cumsum(sizes)[:-1]
+        blob = rng.integers(0, 256, int(sizes.sum()), dtype=np.uint8)
+        kw = dict(pixels=torch.from_numpy(blob).cuda(), offs=torch.from_numpy(offs).cuda(), hs=torch.from_numpy(hs).cuda(),
+                  ws=torch.from_numpy(ws).cuda(), max_h=int(hs.max()), max_w=int(ws.max()))
+        batches.append((kw, torch.from_numpy(rng.integers(0, NCLS, B)).cuda()))
+    engs = []
+    for _ in range(2):
+        e = Engine(graph.build('resnet18', NCLS), 0, max_batch=B)
+        e.init_weights(seed=5)
+        engs.append(e)
+    seq, pipe = engs
+    for kw, y in batches[:4]:
+        seq.load_rois(**kw)
+        seq.target[:B].copy_(y)
+        seq.train_step(B)
+    seq.load_rois(**batches[4][0])
+    pl = seq.forward_eval(B)
+    seq.run(pl.softmax)
+
+    def stage(e, kw, y):
+        slot, side = e.prefetch_begin()
+        with torch.cuda.stream(side):
+            e.load_rois(slot=slot, **kw)
+            e.tgt_bufs[slot][:B].copy_(y)
+        e.prefetch_end(slot)
+
+    stage(pipe, *batches[0])
+    for k in range(4):
+        pipe.use_prefetched()
+        stage(pipe, *batches[k + 1])
+        pipe.train_step(B)
+    pipe.use_prefetched()
+    pl = pipe.forward_eval(B)
+    pipe.run(pl.softmax)
+    torch.cuda.synchronize()
+    assert {k[1] for k in pipe._plans} == {0, 1}                 # both input slots were used
+    assert torch.equal(seq.P, pipe.P) and torch.equal(seq.RB, pipe.RB)
+    assert torch.equal(seq.loss_sum, pipe.loss_sum)
+    assert torch.equal(seq.probs[:B], pipe.probs[:B])
