@@ -130,13 +130,21 @@ def run_mode_leg(args, local):
                               rois['max_w'], slot=slot)
             eng.prefetch_end(slot)
 
+        pipelined = os.environ.get('IFCBK_BENCH_PIPELINE', '0') != '0'     # default off: see the training leg
+
         def batch(k):
-            # batch k was staged by the previous call; batch k+1 is preprocessed on the side stream beside this forward
-            eng.use_prefetched()
-            stage(k + 1)
+            if pipelined:
+                # batch k was staged by the previous call; batch k+1 is preprocessed on the side stream beside this forward
+                eng.use_prefetched()
+                stage(k + 1)
+            else:
+                s0 = (k * B) % POOL
+                eng.load_rois(rois['pixels'], rois['offs'][s0:s0 + B], rois['hs'][s0:s0 + B], rois['ws'][s0:s0 + B], rois['max_h'],
+                              rois['max_w'])
             p = eng.forward_eval(B)
             eng.run(p.softmax)
-        stage(0)
+        if pipelined:
+            stage(0)
         for k in range(3):
             batch(k)
         torch.cuda.synchronize()
@@ -499,7 +507,8 @@ def main():
             ms = (C.c_float * n)()
             if args.dump_ops:
                 rows = []
-                step(0, ev_all)    # one more fully bracketed single-lane step for the per-op table
+                eng.load_rois(**rois)        # one more fully bracketed single-lane step for the per-op table
+                eng.train_step(B, ev_slot=0, ev_arr=eng.plan(B).step.timed(single_lane=True))
                 torch.cuda.synchronize()
                 eng.ctx.call('ifcbk_program_times', 0, n, ms)
                 for j in range(n):

@@ -463,7 +463,10 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: {
             int mt = 0, cols = 0;
             ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
-            if (mt < 0) snprintf(name, cap, "conv_wgrad_pp<%d>", -mt);
+            if (mt < 0) {
+                const char* dm = getenv("IFCBK_WGRAD_PP_DM");          // the name rocprofv3 lists: <KH, DM>
+                snprintf(name, cap, "conv_wgrad_pp<%d, %d>", -mt, dm && atoi(dm) ? 1 : 0);
+            }
             else if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
             else if (mt == 0) snprintf(name, cap, "conv_wgrad_stem");
             else if (cols) snprintf(name, cap, "conv_wgrad_cols<%d, 4>", mt);
