@@ -149,6 +149,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libifcbk.so not found at %s -- build it with `python -c "import __graft_entry__ as g; '
                                'g.build()"` (hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+        # torch first: it brings its own libamdhip64 and the process must have ONE HIP runtime.  Loaded the other way round
+        # (libifcbk.so, then torch) the library's hipGetDeviceCount saw "no ROCm-capable device" while torch.cuda worked --
+        # build() followed by smoke() in one process hit exactly that
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
@@ -166,7 +170,7 @@ class Context:
         h = _vp()
         rc = self.lib.ifcbk_ctx_create(int(device), C.byref(h))
         if rc != 0:
-            raise RuntimeError('ifcbk_ctx_create(device=%d) failed with %d (no usable HIP device?)' % (device, rc))
+            raise RuntimeError('ifcbk_ctx_create(device=%d) failed with %d: %s' % (device, rc, self.lib.ifcbk_last_error(None).decode()))
         self.h = h
         self.device = device
 

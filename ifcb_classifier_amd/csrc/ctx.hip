@@ -42,17 +42,28 @@ static void maybe_install_backtrace() {
 
 extern "C" const char* ifcbk_version(void) { return "ifcbk 0.1 (gfx950, bf16 MFMA)"; }
 
+static char g_create_err[256] = "no ifcbk_ctx_create call has failed";      // ifcbk_last_error(NULL)
+
 extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     if (!out) return IFCBK_EINVAL;
     *out = nullptr;
     maybe_install_backtrace();
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return IFCBK_EHIP;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device < 0 || device >= n) {
+        snprintf(g_create_err, sizeof(g_create_err), "ifcbk_ctx_create(device=%d): hipGetDeviceCount -> %d device(s), %s", device, n,
+                 hipGetErrorString(e));
+        return IFCBK_EHIP;
+    }
     ifcbk_ctx* c = (ifcbk_ctx*)calloc(1, sizeof(ifcbk_ctx));
     if (!c) return IFCBK_ENOMEM;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(&c->zeros, 4096) != hipSuccess ||
-        hipMemset(c->zeros, 0, 4096) != hipSuccess) {
+    const char* what = "hipSetDevice";
+    e = hipSetDevice(device);
+    if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc(&c->zeros, 4096); }
+    if (e == hipSuccess) { what = "hipMemset"; e = hipMemset(c->zeros, 0, 4096); }
+    if (e != hipSuccess) {
+        snprintf(g_create_err, sizeof(g_create_err), "ifcbk_ctx_create(device=%d): %s: %s", device, what, hipGetErrorString(e));
         free(c);
         return IFCBK_EHIP;
     }
@@ -98,7 +109,7 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
 
 extern "C" size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* c) { return c ? c->ws_bytes : 0; }
 
-extern "C" const char* ifcbk_last_error(ifcbk_ctx* c) { return c ? c->err : "null ctx"; }
+extern "C" const char* ifcbk_last_error(ifcbk_ctx* c) { return c ? c->err : g_create_err; }
 
 static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
     void* const* p = o->p;
