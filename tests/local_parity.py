@@ -24,10 +24,13 @@ def check_plan(hip, N, mask=None, verbose=False):
     expected = {}      # buf id -> expected total gradient (NCHW fp32)
     worst = dict(raw=0.0, raw_cp=0.0, y=0.0, dW=0.0, dW_cp=0.0, dgamma=0.0, dbeta=0.0, pool=0.0, head=0.0, dx=0.0, stats=0.0)
 
+    relu_out = {}      # buf id -> [(coff, C, activation)]: conv(+bias)+ReLU outputs whose stored gradient is already masked in place
+
     def add_expected(view, g):
-        assert view.is_full
-        bid = view.buf.id
-        expected[bid] = g if bid not in expected else expected[bid] + g
+        b = view.buf
+        if b.id not in expected:
+            expected[b.id] = torch.zeros(N, b.C, b.H, b.W)
+        expected[b.id][:, view.coff:view.coff + view.C] += g
 
     def upd(k, e, name):
         if verbose:
@@ -89,6 +92,67 @@ def check_plan(hip, N, mask=None, verbose=False):
             upd('pool', rel(act(n.y), O.pool_fwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw))), n.name)
             if n not in fused_y:
                 add_expected(n.x, O.pool_bwd(n.kind, x, (n.R, n.S), (n.sh, n.sw), (n.ph, n.pw), grd(n.y)))
+        elif n.kind == 'cb':
+            # conv (+bias) (+ReLU) without BatchNorm, nn.Linear as a 1x1 conv: ONE stored tensor; its gradient buffer holds
+            # dz = dy * (y > 0) (masked in place by ifcbk_bias_relu_bwd)
+            x = act(n.x)
+            if n.x.buf.is_input:
+                x = x[:, :3]
+            w = P[n.key + '.weight']
+            if w.dim() == 2:
+                w = w[:, :, None, None]
+            kr = n.K_real
+            bias = P[n.key + '.bias'] if n.bias else None
+            stride, pad = (n.sh, n.sw), (n.ph, n.pw)
+            y_h = act(n.y)
+            y_ref = torch.nn.functional.conv2d(x, O.bf16_round(w), bias, stride, pad)
+            y_ref = O.bf16_round(torch.relu(y_ref) if n.relu else y_ref)
+            upd('y', rel(y_h[:, :kr], y_ref), n.name)
+            if kr != n.K:
+                assert float(y_h[:, kr:].abs().max()) == 0.0, n.name       # padded output channels stay zero
+            dz = grd(n.y)
+            if n.relu:
+                assert float((dz * (y_h <= 0)).abs().max()) == 0.0, n.name + ': gradient not masked'
+                relu_out.setdefault(n.y.buf.id, []).append((n.y.coff, n.y.C, y_h))
+            if bias is not None:
+                upd('dbeta', rel(G[n.key + '.bias'], dz[:, :kr].sum((0, 2, 3))), n.name)
+            need_dx = not n.x.buf.is_input
+            dw, dx = O.conv_bwd(x, w, dz[:, :kr], stride, pad, need_dx)
+            upd('dW', rel(G[n.key + '.weight'].reshape(dw.shape), dw), n.name)
+            if need_dx:
+                add_expected(n.x, dx)
+        elif n.kind == 'drop':
+            x = act(n.x)
+            m = n.mask[:N].reshape(N, n.x.H, n.x.W, n.x.C).permute(0, 3, 1, 2).float().cpu() * (1.0 / (1.0 - n.p))
+            upd('pool', rel(act(n.y), O.bf16_round(x * m)), n.name)
+            add_expected(n.x, grd(n.y) * m)
+        elif n.kind == 'flat':
+            x = act(n.x)
+            upd('pool', rel(act(n.y).reshape(N, -1), torch.flatten(x, 1)), n.name)
+            add_expected(n.x, grd(n.y).reshape(x.shape))
+        elif n.kind == 'bnr':
+            # BatchNorm -> ReLU in front of a conv (densenet), on a channel slice of the block's concatenation
+            x = act(n.x)
+            gamma, beta = P[n.bn_key + '.weight'], P[n.bn_key + '.bias']
+            y_ref, mean, var = O.bn_act_fwd(x, gamma, beta, n.eps, n.relu)
+            y_h = act(n.y)
+            upd('y', rel(y_h, y_ref), n.name)
+            st_mean = eng.stats[n.st_off:n.st_off + n.K].cpu()
+            st_is = eng.stats[n.st_off + n.st_ld:n.st_off + n.st_ld + n.K].cpu()
+            upd('stats', max(rel(st_mean, mean), rel(st_is, 1.0 / torch.sqrt(var + n.eps))), n.name)
+            d_x, dg, db, _ = O.bn_act_bwd(x, gamma, beta, n.eps, n.relu, None, grd(n.y), y_for_mask=y_h)
+            upd('dgamma', rel(G[n.bn_key + '.weight'], dg), n.name)
+            upd('dbeta', rel(G[n.bn_key + '.bias'], db), n.name)
+            add_expected(n.x, d_x)
+        elif n.kind == 'head' and not n.fc:
+            # squeezenet: the pooled channels of the classifier conv ARE the logits
+            x = act(n.x)
+            logits = x.mean((2, 3))[:, :n.NC]
+            upd('head', rel(n.logits[:N].cpu(), logits), n.name + ':logits')
+            dl = n.dlogits[:N].cpu()
+            dx = torch.zeros_like(x)
+            dx[:, :n.NC] = (dl / float(n.HW))[:, :, None, None]
+            add_expected(n.x, O.bf16_round(dx))
         elif n.kind == 'head':
             x = act(n.x)
             W, b = P[n.key + '.weight'], P[n.key + '.bias']
@@ -102,5 +166,7 @@ def check_plan(hip, N, mask=None, verbose=False):
             add_expected(n.x, dx)
     for bid, g in expected.items():
         b = net.bufs[bid]
+        for coff, Cc, y_h in relu_out.get(bid, ()):
+            g[:, coff:coff + Cc] *= (y_h > 0).to(g.dtype)
         upd('dx', rel(_nchw(eng.grad[bid], b.full(), N), g), b.name)
     return worst

@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from local_parity import rel
+from local_parity import check_plan, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -157,6 +157,44 @@ def test_family_bf16_against_the_bf16_storage_oracle(name, nc, B, bn):
     with torch.no_grad():
         assert torch.equal(hip(x.cuda()).cpu(), eh)
     assert 'fwd_eval' in hip.engine.plan(B).graphs
+
+
+@pytest.mark.parametrize('name,nc,B,bn', CASES)
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_family_node_local_parity(name, nc, B, bn, dtype):
+    """every node of the plan -- conv+bias+ReLU outputs, Linear layers, dropout, flatten, pre-activation BatchNorm on
+    concatenation slices, pools, heads, every parameter gradient and every summed activation gradient -- against the node-level
+    oracle on the HIP path's OWN inputs (tests/local_parity.py): tight in bf16 too, where end-to-end gradients are not comparable"""
+    from oracle import ops as O
+    hip, ora = _pair(name, nc, B, dtype)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, nc, (B,), generator=g)
+    mo, mh = _masks(name, B, g)
+    if mh is not None:
+        hip.set_dropout_mask(mh)
+    hip.train()
+    F.cross_entropy(hip(x.cuda()), y.cuda()).backward()
+    torch.cuda.synchronize()
+    O.set_storage(dtype)
+    try:
+        worst = check_plan(hip, B)
+    finally:
+        O.set_storage('bf16')
+    print(name, dtype, 'node-local worst rel errors:', {k: '%.1e' % v for k, v in worst.items()})
+    if dtype == 'fp32':
+        # densenet's norm0.weight: the gradient that reaches the first BatchNorm through 120 layers is nearly uncorrelated with
+        # the normalised activation, sum(dz * xhat) over 37,632 pixels cancels to ~1e-5 of its terms and the fp32 summation ORDER
+        # (tile partials here, a running sum in autograd) shows: 4e-2 on that one tensor, with or without the pool fusion, while
+        # dbeta / dW / the activation gradient of the same node agree to 1e-5 (scripts/dbg_family_nodes.py)
+        dg = worst.pop('dgamma')
+        assert dg < (0.1 if name.startswith('densenet') else 5e-5)
+        assert max(worst.values()) < 5e-5
+    else:
+        # 'y' of a conv+bias+ReLU layer: the GEMM epilogue stages the tile through LDS in the storage type, so the bias is added to
+        # the ROUNDED accumulator (two roundings; the single-rounded reference differs by one bf16 ulp on many elements: 3.4e-3)
+        assert worst['y'] < 5e-3 and worst['raw'] < 3e-3 and worst['pool'] < 3e-3 and worst['stats'] < 1e-4 and worst['head'] < 1e-4
+        assert worst['dW'] < 1e-2 and worst['dgamma'] < 1e-2 and worst['dbeta'] < 1e-2 and worst['dx'] < 1.5e-2
 
 
 def test_fused_train_step_learns_on_every_family():
