@@ -594,11 +594,13 @@ void launch_big(const ConvArgs& a, hipStream_t st) {
         return;
     }
     if (big_force("IFCBK_CONV_BIG_NPH") != 5) {          // default: two long phases per K-tile; 5 = the fine-grained conv_big
-        if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
+        if (a.bs_tab) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 5>), grid, block, 0, st, a);
+        else if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 0>), grid, block, 0, st, a);
         return;
     }
-    if (a.bs_raw) hipLaunchKernelGGL((conv_big<TN, MT, 3>), grid, block, 0, st, a);
+    if (a.bs_tab) hipLaunchKernelGGL((conv_big<TN, MT, 5>), grid, block, 0, st, a);
+    else if (a.bs_raw) hipLaunchKernelGGL((conv_big<TN, MT, 3>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_big<TN, MT, 0>), grid, block, 0, st, a);
 }
 

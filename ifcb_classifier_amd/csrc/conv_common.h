@@ -94,7 +94,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <class T, int BM, int BN, int NTHREADS, int MODE>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, float* sRed, const int t, const int lane, const int wave,
                                                     const int m0, const int n0, const int mtile) {
-    constexpr bool BSTAT = MODE == 3;
+    constexpr bool BSTAT = MODE == 3 || MODE == 5;        // 3: one producer (a.bs_raw ...), 5: per-chunk producer table (a.bs_tab)
+    constexpr bool BTAB = MODE == 5;
     constexpr int ES = (int)sizeof(T);
     constexpr int CE = 16 / ES;
     constexpr int NW = NTHREADS / 64;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
             const T* braw = nullptr;                 // this thread's chunk of the producing BatchNorm's input, pixel 0
             int bld = 0;
             if (BSTAT) {
-                if (a.bs_tab) {
+                if (BTAB) {
                     const ifcbk_bs_chunk e = a.bs_tab[nn >> 3];
                     const int off = nn & 7;
                     braw = e.raw ? (const T*)e.raw + off : nullptr;
@@ -129,8 +130,6 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                         bsh[j] = braw ? e.stat[3 * e.stat_ld + off + j] : 0.f;
                     }
                 } else {
-                    braw = (const T*)a.bs_raw + nn;
-                    bld = a.bs_ld;
 #pragma unroll
                     for (int j = 0; j < CE; ++j) {
                         bmu[j] = a.bs_mean[nn + j];
@@ -165,10 +164,10 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
             // whole batch are requested before the first is used -- one exposed memory latency per batch instead of per row
             // (an accumulating 1x1 dgrad into a 288-channel block input ran at 1.5 TB/s with a load -> wait -> store loop)
             constexpr int RT = BM / RPP;
-            // BSTAT: the producer's raw chunks of ALL rows of this thread are requested up front (the accumulators are dead by now,
-            // registers are plentiful): with batches of 4 a 256 x 256 tile paid five exposed HBM latencies per thread and the fused
-            // kernel took twice the plain one's time
-            constexpr int UB = BSTAT ? (RT % 8 == 0 ? 8 : 4) : (RT < 8 ? RT : 8);
+            // MODE 3 keeps batches of four raw rows (eight cost conv_igemm<5,..,3> its second resident block: 71 -> 125 us on the 8x8
+            // layers); the table form (one block per CU on the wide tiles, nothing to lose) takes eight where the rows divide
+            // (narrow tiles, <= 96 channels, gain from eight: 35x35 dgrads 0.113 -> 0.099 ms)
+            constexpr int UB = BTAB ? (RT % 8 == 0 ? 8 : 4) : BSTAT ? ((RT % 8 == 0 && BN <= 96) ? 8 : 4) : (RT < 8 ? RT : 8);
             for (int b = 0; b < RT; b += UB) {
                 typename Chunk<T>::raw_t pre[UB], prer[UB], prb[UB];
                 size_t opx[UB];
@@ -187,7 +186,11 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     if (m < a.M) {
                         if (a.accumulate) pre[u] = Chunk<T>::load_raw((const T*)a.y + opx[u] * a.ldy + nn);
                         if (a.ep_scale && a.ep_res) prer[u] = Chunk<T>::load_raw((const T*)a.ep_res + (size_t)m * a.ep_ldr + nn);
-                        if (BSTAT && braw) prb[u] = Chunk<T>::load_raw(braw + opx[u] * bld);
+                        if (BTAB) {
+                            if (braw) prb[u] = Chunk<T>::load_raw(braw + opx[u] * bld);
+                        } else if (BSTAT) {
+                            prb[u] = Chunk<T>::load_raw((const T*)a.bs_raw + opx[u] * a.bs_ld + nn);
+                        }
                     }
                 }
 #pragma unroll
@@ -201,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     T* dst = MODE == 4 ? segbase + opx[u] * segld : (T*)a.y + opx[u] * a.ldy + nn;
                     float fv[CE];
                     if (a.part || a.accumulate || a.ep_scale) Chunk<T>::widen(rawc, fv);
-                    if (BSTAT && braw) {
+                    if (BSTAT && (!BTAB || braw)) {
                         float fx[CE];
                         Chunk<T>::widen(prb[u], fx);
 #pragma unroll

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
 
     // 1x1 filter without padding (most layers of the inception / resnet graphs): the gather is a plain row read --
     // per-lane offsets are constants and the k advance is a scalar (soffset): no per-step VALU address work at all
-    const bool plain = (MODE == 0 || MODE == 3 || MODE == 4) && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
+    const bool plain = (MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5) && a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
     unsigned va[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) va[j] = bh[j] >= 0 ? (unsigned)(off0[j] + csrc * CE) * (unsigned)ES : OOB;
@@ -512,6 +512,7 @@ void launch(const ConvArgs& a, hipStream_t st) {
     int tilesM = cdiv(a.M, 64 * WM);
     dim3 grid((unsigned)(tilesM * a.tilesN)), block(128 * WM);
     if (a.seg_n) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 4>), grid, block, 0, st, a);
+    else if (a.bs_tab) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 5>), grid, block, 0, st, a);
     else if (a.bs_raw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 3>), grid, block, 0, st, a);
     else if (a.wKg) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 2>), grid, block, 0, st, a);
     else if (a.ish | a.isw) hipLaunchKernelGGL((conv_igemm<T, NT, WM, NSTAGE, 1>), grid, block, 0, st, a);

@@ -458,7 +458,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
                 int bmt = 0, btn = 0;
                 if (!s2 && ifcbk_conv_big_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, &bmt, &btn)) {
-                    snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? 3 : 0);
+                    snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB ? 5 : 0);
                     break;
                 }
                 if (o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && !s2 && ifcbk_conv_ws_shape(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K)) {
@@ -467,7 +467,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 }
                 const bool classes = d.stride_h == 2 && d.stride_w == 2 && d.R >= 2 && d.S >= 2 && d.H >= 2 && d.W >= 2;
                 snprintf(name, cap, "conv_igemm<unsigned short, %d, %d, %d, %d>", ifcbk_conv_fwd_nt(d.C, classes ? d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2) : d.N * d.H * d.W), wm, wm == 4 ? 3 : 2,
-                         (o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? 3 : classes ? 2 : (s2 ? 1 : 0));
+                         o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB ? 5 : classes ? 2 : (s2 ? 1 : 0));
             }
             break;
         }
