@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libifcbk.so')
+LIB_PATH = os.environ.get('IFCBK_LIB') or os.path.join(_HERE, 'libifcbk.so')     # IFCBK_LIB: another build of the library (same-box A/B of kernel variants)
 
 BF16, F32 = 0, 1
 
