@@ -2,7 +2,7 @@
 // input gradient of both (a 3x3 convolution of dy with the flipped filter).
 //
 // As an implicit GEMM these layers re-read every input pixel 9 times from L2 for a 128 x 32 tile (25 flop per loaded
-// byte; 268-386 TF/s, 1.9 TB/s of L2->LDS traffic -- DESIGN.md 5.1).  Here a block walks down the output rows of one
+// byte; 268-386 TF/s, 1.9 TB/s of L2->LDS traffic -- DESIGN.md 5-r1.1).  Here a block walks down the output rows of one
 // image: each INPUT row is brought to LDS once (LDS-DMA, zero-filled outside the image by the buffer range check), stays
 // for the three output rows that use it (4-slot ring, the next row is in flight while a row is multiplied), and all nine
 // taps are MFMA operands read at shifted pixel addresses.  The filter lives in registers (MFMA A operand, loaded once

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_cols(WgradArgs a) {
 // ---------------------------------------------------------------- row-streaming weight gradient of the 3x3 stem layers
 // Conv2d_2a / 2b (32 input channels, 149^2 / 147^2 maps): as a GEMM over (r,s,c) columns the kernels above re-read every
 // input pixel nine times (once per tap) and every dy pixel three times (once per 128-column tile) from L2 -- 3.9 GB of
-// L2->LDS traffic for 1.06 GB of tensors, which is what bounds them (DESIGN.md 5.1).  Here a block walks down output rows
+// L2->LDS traffic for 1.06 GB of tensors, which is what bounds them (DESIGN.md 5-r1.1).  Here a block walks down output rows
 // like conv_rows3x3: every x row goes to LDS ONCE (4-slot ring, chunk-column layout, one zero pixel left of the image) and
 // serves the three output rows and nine taps that use it, every dy row once (2 slots).  The taps are the same transposing
 // fragment reads at shifted pixel addresses (a pixel shift is a uniform 16-byte address shift in the chunk-column layout, so
