@@ -158,8 +158,8 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* conv_args, int mt, int tn, hipSt
 bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh, int* nsplit, int* split_len);
 int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
                           int split_len, hipStream_t st);
-// conv_flat.hip: flat-image kernel for stride-1 3x3 / 5x5 layers with 48..96 channels; segments = grid = BatchNorm partial rows (0: not served)
-int ifcbk_conv_flat_segments(int dtype, int N, int H, int W, int cin, int kout, int R, int S, int ph, int pw, int P, int Q);
+// conv_flat.hip: flat-image kernel for stride-1 3x3 / 5x5 layers with 48..96 channels; returns its BatchNorm partial rows (= persistent grid; 0: not served)
+int ifcbk_conv_flat_rows(int dtype, int N, int H, int W, int cin, int kout, int R, int S, int ph, int pw, int P, int Q);
 int ifcbk_conv_flat_launch(ifcbk_ctx* ctx, void* conv_args, int N, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K, int M);
 bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg);     // the persistent warp-specialised kernel serves this GEMM shape

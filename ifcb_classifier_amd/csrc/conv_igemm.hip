@@ -565,10 +565,10 @@ bool big_ok(const ConvArgs& a) { return !a.wKg && !(a.ish | a.isw); }
 
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;
-    if (!a.wKg && !(a.ish | a.isw) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && a.PQ > 0) {
+    if (!a.wKg && !(a.ish | a.isw) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && !a.accumulate && !a.ep_res && a.PQ > 0) {
         // stride-1 3x3 / 5x5 layers over 48..96 channels: the flat-image kernel (conv_flat.hip)
         const int N = a.M / a.PQ;
-        if (ifcbk_conv_flat_segments(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
+        if (ifcbk_conv_flat_rows(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
             return ifcbk_conv_flat_launch(ctx, &a, N, st);
     }
     {
@@ -638,7 +638,7 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     if (fwd_rows(d)) return ifcbk_conv_rows_blocks(d->N, d->P);
     int M = d->N * d->P * d->Q;
     if (d->stride_h == 1 && d->stride_w == 1)
-        if (int fs = ifcbk_conv_flat_segments(d->dtype, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->pad_h, d->pad_w, d->P, d->Q)) return fs;
+        if (int fs = ifcbk_conv_flat_rows(d->dtype, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->pad_h, d->pad_w, d->P, d->Q)) return fs;
     {
         int bmt = 0, btn = 0;
         if (ifcbk_conv_big_plan(d->dtype, M, d->K, d->R * d->S * d->C, &bmt, &btn)) return cdiv(M, 32 * bmt);
@@ -741,7 +741,7 @@ extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, cons
 extern "C" int ifcbk_conv2d_dgrad_bnstat_mblocks(const ifcbk_conv_desc* d) {
     if (!d || !dgrad_bnstat_ok(d)) return 0;
     int M = d->N * d->H * d->W;
-    if (int fs = ifcbk_conv_flat_segments(d->dtype, d->N, d->P, d->Q, d->K, d->C, d->R, d->S, d->R - 1 - d->pad_h, d->S - 1 - d->pad_w, d->H, d->W)) return fs;
+    if (int fs = ifcbk_conv_flat_rows(d->dtype, d->N, d->P, d->Q, d->K, d->C, d->R, d->S, d->R - 1 - d->pad_h, d->S - 1 - d->pad_w, d->H, d->W)) return fs;
     {
         int bmt = 0, btn = 0;
         if (ifcbk_conv_big_plan(d->dtype, M, d->C, d->R * d->S * d->K, &bmt, &btn)) return cdiv(M, 32 * bmt);

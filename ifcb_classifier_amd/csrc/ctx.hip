@@ -435,8 +435,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int wm = ifcbk_conv_fwd_wm(d.N * d.P * d.Q, d.K);
             int bmt = 0, btn = 0;
             const bool rows = ifcbk_conv_rows_ok(d.dtype, d.C, d.K, d.R, d.S, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.Q) && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]);
-            if (!rows && d.stride_h == 1 && d.stride_w == 1 &&
-                ifcbk_conv_flat_segments(d.dtype, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.pad_h, d.pad_w, d.P, d.Q)) {
+            if (!rows && d.stride_h == 1 && d.stride_w == 1 && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]) &&
+                ifcbk_conv_flat_rows(d.dtype, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.pad_h, d.pad_w, d.P, d.Q)) {
                 snprintf(name, cap, "conv_flat<%d, %d, %d, %d, 0>", d.C, d.K, d.R, d.S);
                 break;
             }
@@ -461,8 +461,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                     break;
                 }
                 const bool s2 = d.stride_h == 2 || d.stride_w == 2;
-                if (!s2 && o->kind != IFCBK_OP_CONV_DGRAD_BNSTAT_TAB &&
-                    ifcbk_conv_flat_segments(d.dtype, d.N, d.P, d.Q, d.K, d.C, d.R, d.S, d.R - 1 - d.pad_h, d.S - 1 - d.pad_w, d.H, d.W)) {
+                if (!s2 && o->kind != IFCBK_OP_CONV_DGRAD_BNSTAT_TAB && !(o->kind == IFCBK_OP_CONV_DGRAD && (o->flags & 1)) &&
+                    ifcbk_conv_flat_rows(d.dtype, d.N, d.P, d.Q, d.K, d.C, d.R, d.S, d.R - 1 - d.pad_h, d.S - 1 - d.pad_w, d.H, d.W)) {
                     snprintf(name, cap, "conv_flat<%d, %d, %d, %d, %d>", d.K, d.C, d.R, d.S, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
                     break;
                 }

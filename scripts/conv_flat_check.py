@@ -124,7 +124,7 @@ for name in which:
                 e1.record(); torch.cuda.synchronize()
                 ms[flat].append(e0.elapsed_time(e1) / 3)
         m0, m1 = min(ms['0']), min(ms['2'])
-        ok = outs['2'][2] < 5e-3 and outs['2'][3] < 2e-4 and 'conv_flat' in outs['2'][0]
+        ok = outs['2'][2] < 5e-3 and outs['2'][3] < 2e-4 and ('conv_flat' in outs['2'][0] or mode == 'dgrad_acc')
         print('%-8s %-9s old %-36s %7.3f ms %5.0f TF | new %-30s %7.3f ms %5.0f TF x%.2f | err old %.1e new %.1e stat %.1e / %.1e %s'
               % (name, mode, outs['0'][0], m0, flops / m0 / 1e9, outs['2'][0], m1, flops / m1 / 1e9, m0 / m1, outs['0'][2], outs['2'][2],
                  outs['0'][3], outs['2'][3], 'OK' if ok else 'BAD'), flush=True)
