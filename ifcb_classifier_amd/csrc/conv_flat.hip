@@ -57,8 +57,9 @@ __device__ __forceinline__ int flat_swz(int px, int ch) {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-// KPS: 32-k MFMA steps per ring stage (4: one barrier per 128 k)
-template <int CIN, int KOUT, int R, int S, int WM, int WN, int MT, int KPS, int WPMAX, int MODE>
+// KPS: 32-k MFMA steps per ring stage; NSTAGE: ring slots (the loaders run NSTAGE-1 stages ahead: with one stage ahead the loop ran at the
+// LDS-DMA round trip, ~1,600 cycles per stage, whatever the consumers did)
+template <int CIN, int KOUT, int R, int S, int WM, int WN, int MT, int KPS, int NSTAGE, int WPMAX, int MODE>
 __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
     typedef bf16_t T;
     typedef bf16x8_t frag_t;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
     constexpr int NPIECE = ((MS + HALO) * CPP + 63) / 64;
     constexpr int IMG_BYTES = NPIECE * 1024;
     constexpr int NLW = 4;                            // loader waves
-    constexpr int IPS = (NPIECE + NLW * (NK - 1) - 1) / (NLW * (NK - 1));   // pieces of the next image per loader wave and stage
+    constexpr int D = NSTAGE - 1;                     // stages the filter ring runs ahead
+    constexpr int IPS = (NPIECE + NLW * (NK - D) - 1) / (NLW * (NK - D));   // pieces of the next image per loader wave and stage
     constexpr int KI = (NPIECE + NLW * IPS - 1) / (NLW * IPS);     // ... in the first KI stages of a segment
     constexpr int SUB_BYTES = KOUT * 128;
     constexpr int BSTAGE = NSUB * SUB_BYTES;
@@ -83,14 +85,14 @@ __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
     constexpr int JB = (NBP + NLW - 1) / NLW;         // per loader wave
     constexpr int PAR_BYTES = 4 * KOUT * 4;           // per-channel parameters of the epilogue (affine / BN-backward), fp32
     constexpr int RED_BYTES = 4 * 2 * KOUT * 4;       // statistics hand-over between the consumer waves at the very end
-    constexpr int SMEM_BYTES = 2 * IMG_BYTES + 2 * BSTAGE + PAR_BYTES + RED_BYTES + 1024;
+    constexpr int SMEM_BYTES = 2 * IMG_BYTES + NSTAGE * BSTAGE + PAR_BYTES + RED_BYTES + 1024;
     static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
-    static_assert(JR >= 4 && KI <= NK - 1, "a segment's last stage carries no image piece: stage 0 of the next waits for all of them");
+    static_assert(JR >= 4 && D >= 1 && D <= 3 && NK > D && KI <= NK - D, "a segment's last D stages carry no image piece: stage 0 of the next waits for all of them");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* sRingB = smem + 2 * IMG_BYTES;
-    float* sPar = reinterpret_cast<float*>(smem + 2 * IMG_BYTES + 2 * BSTAGE);
-    float* sRed = reinterpret_cast<float*>(smem + 2 * IMG_BYTES + 2 * BSTAGE + PAR_BYTES);
-    unsigned char* sDummy = smem + 2 * IMG_BYTES + 2 * BSTAGE + PAR_BYTES + RED_BYTES;
+    float* sPar = reinterpret_cast<float*>(smem + 2 * IMG_BYTES + NSTAGE * BSTAGE);
+    float* sRed = reinterpret_cast<float*>(smem + 2 * IMG_BYTES + NSTAGE * BSTAGE + PAR_BYTES);
+    unsigned char* sDummy = smem + 2 * IMG_BYTES + NSTAGE * BSTAGE + PAR_BYTES + RED_BYTES;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -117,70 +119,95 @@ __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
         const int np = ((MS + (R - 1) * f.Wp + S - 1) * CPP + 63) >> 6;      // pieces of a segment image (<= NPIECE: Wp <= WPMAX)
         // one LDS-DMA piece (64 chunks in image order) of the image of the segment that starts at slot g0
-        auto issue_piece = [&](unsigned g0, int pc, unsigned char* buf, bool live) {
-            const int idx = pc * 64 + lane;
-            const int lpx = idx / CPP;
-            const int phys = idx - lpx * CPP;
-            const int logical = flat_swz<CPP>(lpx, phys);
-            const unsigned F = g0 + (unsigned)lpx;
+        // This wave's pieces of an image are pc = lw, lw + 4, ...: the lane's position (pixel lpx of the image, chunk phys, and
+        // that pixel's image / row / column in the flat layout) is decoded ONCE per segment (two divisions) and then stepped
+        // from piece to piece with adds and carries -- a decode per piece cost the loaders more VALU time than the DMAs themselves
+        constexpr int DL = (NLW * 64) / CPP, PH = (NLW * 64) % CPP;
+        int i_lpx, i_phys, i_n, i_hr, i_wc;
+        auto piece_begin = [&](unsigned g0) {
+            const int idx = lw * 64 + lane;
+            i_lpx = idx / CPP;
+            i_phys = idx - i_lpx * CPP;
+            const unsigned F = g0 + (unsigned)i_lpx;
             const unsigned n = fdiv(F, f.fHW);
             const unsigned rem = F - n * (unsigned)f.HpWp;
             const unsigned hr = fdiv(rem, f.fW);
-            const int w = (int)(rem - hr * (unsigned)f.Wp) - f.pw;
-            const int h = (int)hr - f.ph;
-            const bool v = live && n < (unsigned)f.N && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && !FLAT_DBG(1);
-            const unsigned voff = v ? (unsigned)((((int)n * a.H + h) * a.W + w) * a.ldx + logical * 8) * 2u : OOB;
-            lds_dma16(rsA, (lptr_t)(live ? buf + pc * 1024 : sDummy), voff, 0);
+            i_n = (int)n; i_hr = (int)hr; i_wc = (int)(rem - hr * (unsigned)f.Wp);
+        };
+        auto piece_issue = [&](unsigned char* dst, bool live) {       // the current piece, then step to this wave's next one
+            const int w = i_wc - f.pw, h = i_hr - f.ph;
+            const bool v = live && i_n < f.N && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && !FLAT_DBG(1);
+            const unsigned voff = v ? (unsigned)(((i_n * a.H + h) * a.W + w) * a.ldx + flat_swz<CPP>(i_lpx, i_phys) * 8) * 2u : OOB;
+            lds_dma16(rsA, (lptr_t)(live ? dst : sDummy), voff, 0);
+            int dl = DL;
+            i_phys += PH;
+            if (i_phys >= CPP) { i_phys -= CPP; ++dl; }
+            i_lpx += dl;
+            i_wc += dl;
+            while (i_wc >= f.Wp) { i_wc -= f.Wp; ++i_hr; }
+            while (i_hr >= f.Hp) { i_hr -= f.Hp; ++i_n; }
         };
         // filter: a stage is NSUB sub-tiles [KOUT rows][8 chunks], chunk c of row r at physical chunk c ^ (r & 7) (source side)
         const int lrow8 = lane >> 3;
         const int csrc = (lane & 7) ^ lrow8;
-        int prow[JB], psub[JB];
-        bool glive[JB];
+        unsigned woff[JB];                                  // this lane's chunk of stage 0 (bytes); a stage advances KPS*64 bytes: scalar offset
+        bool glive[JB], gtail[JB];                          // piece exists / this lane's chunk of a segment's LAST stage lies inside the filter row
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int grp = j * NLW + lw;                   // piece of the stage: sub-tile grp / (KOUT/8), row group grp % (KOUT/8)
             glive[j] = grp < NBP;
-            psub[j] = grp / (KOUT / 8);
-            prow[j] = (grp - psub[j] * (KOUT / 8)) * 8 + lrow8;
+            const int psub = grp / (KOUT / 8);
+            const int prow = (grp - psub * (KOUT / 8)) * 8 + lrow8;
+            woff[j] = glive[j] ? (unsigned)(prow * a.Kg + (psub * 8 + csrc) * 8) * 2u : OOB;
+            gtail[j] = ((NK - 1) * NSUB + psub) * 8 + csrc < NCH;
         }
         // stage kt of a segment: chunks kt*KPS*4 .. of every filter row; chunks past the row's end (last stage) read zeros
 #define FLAT_ISSUE_B(kt, slot)                                                                              \
         _Pragma("unroll") for (int j = 0; j < JB; ++j) {                                                    \
-            const int chunk = ((kt) * NSUB + psub[j]) * 8 + csrc;                                           \
-            const bool v = glive[j] && chunk < NCH && !FLAT_DBG(2);                                         \
-            const unsigned voff = v ? (unsigned)(prow[j] * a.Kg + chunk * 8) * 2u : OOB;                    \
+            const bool cut = ((kt) == NK - 1 && !gtail[j]) || FLAT_DBG(2);                                  \
             unsigned char* dst = glive[j] ? sRingB + (slot) * BSTAGE + (j * NLW + lw) * 1024 : sDummy;      \
-            lds_dma16(rsB, (lptr_t)dst, voff, 0);                                                           \
+            lds_dma16(rsB, (lptr_t)dst, cut ? OOB : woff[j], (kt) * (KPS * 64));                            \
         }
-        for (int pc = lw; pc < np; pc += NLW) issue_piece((unsigned)bb * MS, pc, smem, true);
-        FLAT_ISSUE_B(0, 0)
+        piece_begin((unsigned)bb * MS);
+        for (int pc = lw; pc < np; pc += NLW) piece_issue(smem + pc * 1024, true);
+#pragma unroll
+        for (int d = 0; d < D; ++d) FLAT_ISSUE_B(d, d)
         wait_vmcnt<0>();
-        int slot = 0;
+        int islot = D;                                      // ring slot the next fetched stage goes to
+        bool first = true;
         for (int it = 0; it < nmine; ++it) {
             const bool has_next = it + 1 < nmine;
-            const unsigned g0n = (unsigned)(bb + (it + 1) * grid) * MS;
             unsigned char* bufn = smem + ((it + 1) & 1) * IMG_BYTES;
+            piece_begin((unsigned)(bb + (it + 1) * grid) * MS);
             for (int kt = 0; kt < NK; ++kt) {
-                // stage kt has landed once only the image pieces issued behind it (in the previous stage) are outstanding
-                if (it > 0 || kt > 0) {
-                    const int kp = kt == 0 ? NK - 1 : kt - 1;
-                    if (kp < KI) wait_vmcnt<IPS>();
-                    else wait_vmcnt<0>();
+                // Stage kt has landed once only the loads issued BEHIND its pieces are outstanding: the D-1 later filter stages and
+                // the image pieces of the last D stage bodies (a body issues filter stage +D, then its image pieces)
+                if (!first) {
+                    int c = 0;
+#pragma unroll
+                    for (int d = 1; d <= D; ++d) {
+                        const int kp = kt - d < 0 ? kt - d + NK : kt - d;
+                        c += kp < KI ? 1 : 0;
+                    }
+                    if (c == 0) wait_vmcnt<(D - 1) * JB>();
+                    else if (c == 1) wait_vmcnt<(D - 1) * JB + IPS>();
+                    else if (c == 2) wait_vmcnt<(D - 1) * JB + 2 * IPS>();
+                    else wait_vmcnt<(D - 1) * JB + 3 * IPS>();
                 }
+                first = false;
                 __builtin_amdgcn_s_barrier();       // stage kt is in LDS; the consumers have finished stage kt-1 (its slot is free)
                 {
-                    const int ktn = kt + 1 == NK ? 0 : kt + 1;         // running on into the next segment (the last one refetches stage 0: unused)
-                    FLAT_ISSUE_B(ktn, slot ^ 1)
+                    const int ktn = kt + D >= NK ? kt + D - NK : kt + D;      // running on into the next segment (the last one refetches early stages: unused)
+                    FLAT_ISSUE_B(ktn, islot)
+                    islot = islot + 1 == NSTAGE ? 0 : islot + 1;
                 }
                 if (kt < KI) {
 #pragma unroll
                     for (int u = 0; u < IPS; ++u) {
                         const int pc = (kt * IPS + u) * NLW + lw;
-                        issue_piece(g0n, pc, bufn, has_next && pc < np);
+                        piece_issue(bufn + pc * 1024, has_next && pc < np);
                     }
                 }
-                slot ^= 1;
             }
         }
 #undef FLAT_ISSUE_B
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
                         }
                     }
             }
-            slot ^= 1;
+            slot = slot + 1 == NSTAGE ? 0 : slot + 1;
         }
         // ---- this segment's tile: rounded to the storage type in registers, statistics of the rounded values
 #pragma unroll
@@ -418,12 +445,12 @@ int flat_grid(int nseg) {
     return nseg < cus ? nseg : cus;
 }
 
-template <int CIN, int KOUT, int R, int S, int WM, int WN, int MT, int KPS>
+template <int CIN, int KOUT, int R, int S, int WM, int WN, int MT, int KPS, int NSTAGE>
 int launch_flat(const ConvArgs& a, const FlatArgs& f, int ms, hipStream_t st) {
     if (ms != 16 * MT * WM) return -1;
     const dim3 grid((unsigned)flat_grid(f.nseg)), block(512);
-    if (a.bs_raw) hipLaunchKernelGGL((conv_flat<CIN, KOUT, R, S, WM, WN, MT, KPS, FLAT_WPMAX, 3>), grid, block, 0, st, a, f);
-    else hipLaunchKernelGGL((conv_flat<CIN, KOUT, R, S, WM, WN, MT, KPS, FLAT_WPMAX, 0>), grid, block, 0, st, a, f);
+    if (a.bs_raw) hipLaunchKernelGGL((conv_flat<CIN, KOUT, R, S, WM, WN, MT, KPS, NSTAGE, FLAT_WPMAX, 3>), grid, block, 0, st, a, f);
+    else hipLaunchKernelGGL((conv_flat<CIN, KOUT, R, S, WM, WN, MT, KPS, NSTAGE, FLAT_WPMAX, 0>), grid, block, 0, st, a, f);
     return 0;
 }
 
@@ -468,11 +495,11 @@ int ifcbk_conv_flat_launch(ifcbk_ctx* ctx, void* args, int N, hipStream_t st) {
 #endif
     int rc;
     switch (i) {
-        case 0: rc = launch_flat<48, 64, 5, 5, 4, 1, 4, 4>(a, f, kFlat[i].ms, st); break;
-        case 1: rc = launch_flat<64, 48, 5, 5, 4, 1, 4, 4>(a, f, kFlat[i].ms, st); break;
-        case 2: rc = launch_flat<64, 96, 3, 3, 2, 2, 6, 4>(a, f, kFlat[i].ms, st); break;
-        case 3: rc = launch_flat<96, 64, 3, 3, 4, 1, 3, 4>(a, f, kFlat[i].ms, st); break;
-        default: rc = launch_flat<96, 96, 3, 3, 2, 2, 6, 4>(a, f, kFlat[i].ms, st); break;
+        case 0: rc = launch_flat<48, 64, 5, 5, 4, 1, 4, 2, 4>(a, f, kFlat[i].ms, st); break;
+        case 1: rc = launch_flat<64, 48, 5, 5, 4, 1, 4, 2, 4>(a, f, kFlat[i].ms, st); break;
+        case 2: rc = launch_flat<64, 96, 3, 3, 2, 2, 6, 2, 4>(a, f, kFlat[i].ms, st); break;
+        case 3: rc = launch_flat<96, 64, 3, 3, 4, 1, 3, 2, 4>(a, f, kFlat[i].ms, st); break;
+        default: rc = launch_flat<96, 96, 3, 3, 2, 2, 6, 2, 4>(a, f, kFlat[i].ms, st); break;
     }
     if (rc) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_flat: table / template mismatch");
     IFCBK_LAUNCH_CHECK(ctx, "conv_flat");
