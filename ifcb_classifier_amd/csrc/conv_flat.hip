@@ -10,14 +10,14 @@
 // slot g = (n*Hp + p)*Wp + q, and tap (r, s) of ANY output slot reads slot g + r*Wp + s: every tap is a constant shift.  A
 // SEGMENT of MS consecutive output slots needs the MS + (R-1)*Wp + S-1 input slots behind it: they come to LDS ONCE (LDS-DMA,
 // zeros outside the image through the buffer range check) and all R*S*C/32 pixel fragments of the reduction are read from that
-// resident image at shifted addresses; only the filter (L2-resident, k-contiguous rows) streams through a two-stage ring.
+// resident image at shifted addresses; only the filter (L2-resident, k-contiguous rows) streams through a two-slot ring.
 // Global->LDS traffic per MAC: 1/4 of the implicit GEMM's.  Outputs at padding slots (q >= Q or p >= P: 5-11 % of the slots)
 // are computed and dropped.
 //
 // Structure (from s_memtime stamps and timing-only builds of two earlier forms): a block that loads its image,
 // multiplies and writes its tile out in turn spends as long in the load and store phases as in the MFMAs (a CU streams
 // 5-10 B/clk to memory, whoever else is busy: 37 KB of outputs = 8,500 cycles against 8,000 cycles of MFMA), a second resident
-// block hides little of that, and an LDS-DMA instruction costs its wave ~140 issue cycles.  So: ONE PERSISTENT 512-thread block
+// block hides little of that, and an LDS-DMA instruction costs its wave ~200 issue cycles.  So: ONE PERSISTENT 512-thread block
 // per CU walks over its segments with its waves SPECIALISED --
 //   waves 4-7, loaders: every LDS-DMA of the block (filter stage s+1 and a share of the NEXT segment's image while stage s is
 //     multiplied; counted vmcnt, one s_barrier per stage is the whole protocol); they never store, so no wait drains a store;
@@ -57,8 +57,9 @@ __device__ __forceinline__ int flat_swz(int px, int ch) {
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-// KPS: 32-k MFMA steps per ring stage; NSTAGE: ring slots (the loaders run NSTAGE-1 stages ahead: with one stage ahead the loop ran at the
-// LDS-DMA round trip, ~1,600 cycles per stage, whatever the consumers did)
+// KPS: 32-k MFMA steps per ring stage; NSTAGE: ring slots (the loaders run NSTAGE-1 stages ahead).  Shipped: 128-k stages, two slots;
+// 64-k stages with four slots measured 10 % slower -- the loaders are bound by the number of LDS-DMA instructions (~200 cycles each
+// for the issuing wave, at any depth), not by their latency
 template <int CIN, int KOUT, int R, int S, int WM, int WN, int MT, int KPS, int NSTAGE, int WPMAX, int MODE>
 __global__ __launch_bounds__(512) void conv_flat(ConvArgs a, FlatArgs f) {
     typedef bf16_t T;
@@ -427,8 +428,7 @@ constexpr int FLAT_WPMAX = 40;
 struct FlatShape { int cin, kout, r, s, ms; };
 // instantiations: the 35x35 stage of inception_v3 (forward and input-gradient roles); ms = 16 * MT * WM of launch_flat below
 const FlatShape kFlat[] = {
-    {48, 64, 5, 5, 256},   // Mixed_5x.branch5x5_2 forward
-    {64, 48, 5, 5, 256},   //                      input gradient
+    {64, 48, 5, 5, 256},   // Mixed_5x.branch5x5_2 input gradient (its forward, 48 -> 64, measured no faster than conv_igemm: not built)
     {64, 96, 3, 3, 192},   // branch3x3dbl_2 forward
     {96, 64, 3, 3, 192},   //                input gradient
     {96, 96, 3, 3, 192},   // branch3x3dbl_3 forward and input gradient
@@ -495,11 +495,10 @@ int ifcbk_conv_flat_launch(ifcbk_ctx* ctx, void* args, int N, hipStream_t st) {
 #endif
     int rc;
     switch (i) {
-        case 0: rc = launch_flat<48, 64, 5, 5, 4, 1, 4, 2, 4>(a, f, kFlat[i].ms, st); break;
-        case 1: rc = launch_flat<64, 48, 5, 5, 4, 1, 4, 2, 4>(a, f, kFlat[i].ms, st); break;
-        case 2: rc = launch_flat<64, 96, 3, 3, 2, 2, 6, 2, 4>(a, f, kFlat[i].ms, st); break;
-        case 3: rc = launch_flat<96, 64, 3, 3, 4, 1, 3, 2, 4>(a, f, kFlat[i].ms, st); break;
-        default: rc = launch_flat<96, 96, 3, 3, 2, 2, 6, 2, 4>(a, f, kFlat[i].ms, st); break;
+        case 0: rc = launch_flat<64, 48, 5, 5, 4, 1, 4, 4, 2>(a, f, kFlat[i].ms, st); break;
+        case 1: rc = launch_flat<64, 96, 3, 3, 2, 2, 6, 4, 2>(a, f, kFlat[i].ms, st); break;
+        case 2: rc = launch_flat<96, 64, 3, 3, 4, 1, 3, 4, 2>(a, f, kFlat[i].ms, st); break;
+        default: rc = launch_flat<96, 96, 3, 3, 2, 2, 6, 4, 2>(a, f, kFlat[i].ms, st); break;
     }
     if (rc) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_flat: table / template mismatch");
     IFCBK_LAUNCH_CHECK(ctx, "conv_flat");
