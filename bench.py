@@ -55,7 +55,42 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
+def cpu_baseline_eval(batch=32, budget_s=10.0, seed=1234):
+    """the reference's CPU RUN path restated by the oracle ("train and eval"): PIL L->RGB->resize->ToTensor per ROI,
+    eval forward of the fp32 torch-CPU backbone, softmax (neuston_models.py:152-157); bounded to ~budget_s of CPU work."""
+    import numpy as np
+    from PIL import Image
+    from oracle import tv_models
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    model = tv_models.get_namebrand_model('inception_v3', 100, storage='fp32')
+    model.eval()
+    _, (hs, ws, offs, pix) = synth_rois(batch, seed, 'cpu')
+
+    def step():
+        imgs = []
+        for i in range(batch):
+            a = pix[offs[i]:offs[i] + int(hs[i]) * int(ws[i])].view(int(hs[i]), int(ws[i])).numpy()
+            im = Image.fromarray(a, 'L').convert('RGB').resize((299, 299), Image.BILINEAR)
+            imgs.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float().div(255))
+        with torch.no_grad():
+            return torch.softmax(model(torch.stack(imgs)), 1)
+
+    step()
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= 0.6 * budget_s or steps >= 64 or dt + dt / steps > budget_s:
+            break
+    return dict(value=round(batch * steps / dt, 3), unit='images/s', cores=cores, kind='port',
+                sample='%d eval batches of %d after 1 warm-up (PIL resize + fp32 torch-CPU oracle eval forward + softmax), %.1f s'
+                       % (steps, batch, dt))
+
+
+def cpu_baseline(batch=32, budget_s=25.0, seed=1234):
     """the reference's CPU path restated by the oracle: PIL L->RGB->resize->ToTensor per ROI, then the
     fp32 torch-CPU train step (loss = CE + 0.4 CE_aux, Adam 1e-3; neuston_models.py:63-86).  Bounded: one
     warm-up step, then steps until ~15 s of timed CPU work (at least 1 step; total bounded by budget_s)."""
@@ -90,7 +125,7 @@ def cpu_baseline(batch=16, budget_s=25.0, seed=1234):
     step()
     warm = time.perf_counter() - t0
     print('[cpu_baseline] warm-up step of batch %d on %d threads: %.1f s' % (batch, cores, warm), file=sys.stderr, flush=True)
-    target = min(15.0, max(1.0, budget_s - warm))      # ~15 s of timed CPU work, never more than budget_s in total
+    target = min(12.0, max(1.0, budget_s - warm))      # ~12 s of timed CPU work, never more than budget_s in total
     steps = 0
     t0 = time.perf_counter()
     while True:
@@ -162,7 +197,12 @@ def run_mode_leg(args, local):
     best = max(sweep, key=lambda b: sweep[b]['images_per_s'])
     ips, ms, n = run(int(best), args.infer_rois)
     tf = ips * 11.423e-3
-    return dict(workload='RUN-mode inference, inception_v3 %d-class bf16, %d synthetic ROIs h,w~U{32..299} (windows of a pool of %d '
+    cpu_eval = None
+    if not args.no_cpu_baseline:
+        del eng
+        torch.cuda.empty_cache()
+        cpu_eval = cpu_baseline_eval()
+    return dict(cpu_baseline=cpu_eval, workload='RUN-mode inference, inception_v3 %d-class bf16, %d synthetic ROIs h,w~U{32..299} (windows of a pool of %d '
                          'in HBM), batch %s, hipGraph-replayed eval forward, preprocess + softmax included, file writes excluded '
                          '(BASELINE.json configs[3])' % (args.classes, n, POOL, best),
                 images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), batch=int(best), rois=n, seconds=round(n / ips, 2),
@@ -199,6 +239,61 @@ def fp32_leg(args, local):
                 peak_tflops=157.3, frac_of_fp32_mfma_peak=round(B / dt * TRAIN_GFLOP_PER_IMG * 1e-3 / 157.3, 4),
                 note='parity mode: logits within 1e-3 of the fp32 CPU oracle (train 4e-5, eval 3e-7); the headline value is the bf16 mode, '
                      'whose random-init logits sit inside the bf16-storage envelope of the oracle (DESIGN.md section 4)')
+
+
+def lib_sha16():
+    import hashlib
+    from ifcb_classifier_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()[:16]
+
+
+def stage_of(tag):
+    """network stage of an op by its layer tag (the spatial size the layer's convs work at)"""
+    t = tag.split('+')[0]
+    if t.startswith('Conv2d_') or t.startswith('maxpool') or t.startswith('input'):
+        return 'stem'
+    if t.startswith(('Mixed_5', 'Mixed_6a')):
+        return '35x35'
+    if t.startswith(('Mixed_6', 'Mixed_7a', 'AuxLogits')):
+        return '17x17'
+    if t.startswith('Mixed_7'):
+        return '8x8'
+    return 'head+update'
+
+
+def layer_roofline(eng, pl, nsteps, hbm_tbps=6.29):
+    """per-op roofline of the survey pass (every op alone on the GPU, one lane): MAC-weighted achieved / bound of the conv ops --
+    bound = min(MFMA peak, arithmetic intensity x measured-copy HBM rate), as scripts/layer_roofline.py prints per layer -- and
+    the step's isolated-op time by network stage (comparable across rounds)"""
+    n = pl.step.n
+    ms = (C.c_float * n)()
+    tot = [0.0] * n
+    for k in range(nsteps):
+        eng.ctx.call('ifcbk_program_times', k, n, ms)
+        for j in range(n):
+            tot[j] += ms[j] / nsteps
+    stages, conv_ms, conv_bound_ms, conv_fl = {}, 0.0, 0.0, 0.0
+    for j in range(n):
+        if tot[j] <= 0.0:
+            continue
+        op = pl.step.arr[j]
+        fl, by = C.c_double(), C.c_double()
+        eng.ctx.lib.ifcbk_op_cost(C.byref(op), C.byref(fl), C.byref(by))
+        st = stages.setdefault(stage_of(pl.step.tags[j]), dict(ms=0.0, conv_ms=0.0, conv_gflop=0.0))
+        st['ms'] += tot[j]
+        if fl.value > 0 and by.value > 0 and op.kind in (1, 2, 3, 20, 22, 25, 29, 31):
+            bound = min(MFMA_BF16_PEAK_TFLOPS * 1e12, fl.value / by.value * hbm_tbps * 1e12)
+            conv_ms += tot[j]
+            conv_bound_ms += 1e3 * fl.value / bound
+            conv_fl += fl.value
+            st['conv_ms'] += tot[j]
+            st['conv_gflop'] += fl.value / 1e9
+    return {'conv_mac_weighted_achieved_over_bound': round(conv_bound_ms / conv_ms, 4) if conv_ms else None,
+            'conv_ms_at_roofline': round(conv_bound_ms, 3), 'conv_ms_measured': round(conv_ms, 3),
+            'isolated_ms_by_stage': {k: dict(ms=round(v['ms'], 3), conv_ms=round(v['conv_ms'], 3),
+                                             conv_tflops=round(v['conv_gflop'] / v['conv_ms'], 1) if v['conv_ms'] else None)
+                                     for k, v in sorted(stages.items())},
+            'note': 'survey pass (every op bracketed, one lane, each kernel alone on the GPU); bound = min(2.5 PF, AI x 6.29 TB/s)'}
 
 
 def main():
@@ -463,21 +558,33 @@ def main():
             traffic = None
             mfma_util, prof_src = None, None
 
+            lib_sha = lib_sha16()
+
             def newest(suffix):
-                # the newest committed PMC summary (profiles/r<round><letter>_<suffix>.json) that lists this kernel
+                # the newest committed PMC summary (profiles/r<round><letter>_<suffix>.json, ordered by round number, then letter)
+                # that lists this kernel AND was collected with this very build of libifcbk.so (the collectors record its hash):
+                # a kernel whose body changed under an unchanged name must not inherit stale counters
                 import glob
-                for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s.json' % suffix)), reverse=True):
+                import re
+
+                def order(f):
+                    m = re.match(r'r(\d+)([a-z]*)_', os.path.basename(f))
+                    return (int(m.group(1)), m.group(2)) if m else (-1, '')
+                stale = None
+                for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s.json' % suffix)), key=order, reverse=True):
                     try:
-                        k = json.load(open(f))['kernels']
-                        if dom in k:
-                            return k[dom], os.path.basename(f)
+                        j = json.load(open(f))
+                        if dom in j['kernels']:
+                            if j.get('lib_sha16') == lib_sha:
+                                return j['kernels'][dom], os.path.basename(f), None
+                            stale = stale or os.path.basename(f)
                     except Exception:
                         pass
-                return None, None
-            ent, src = newest('traffic')    # HBM bytes per launch from two separate --pmc passes (scripts/collect_traffic.py)
+                return None, None, stale
+            ent, src, stale_t = newest('traffic')    # HBM bytes per launch from two separate --pmc passes (scripts/collect_traffic.py)
             if ent:
                 traffic, prof_src = round(ent['hbm_bytes_per_launch']), src
-            ent, src = newest('mfma')       # MFMA-pipe busy fraction from its own --pmc pass (scripts/collect_mfma.py)
+            ent, src, stale_m = newest('mfma')       # MFMA-pipe busy fraction from its own --pmc pass (scripts/collect_mfma.py)
             if ent:
                 mfma_util = round(ent['mfma_pipe_utilisation'], 4)
             out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
@@ -491,7 +598,13 @@ def main():
                                if use_ev else 'N > 1: rank 0, untimed survey pass (3 local steps, every op bracketed, one lane)',
                                'isolated_tflops': round(survey[dom]['flops'] / (survey[dom]['ms'] * 1e-3) / 1e12, 2),
                                'isolated_avg_launch_ms': round(survey[dom]['ms'] / survey[dom]['launches'], 5),
-                               'pmc_mfma_pipe_utilisation': mfma_util, 'pmc_source': prof_src}
+                               'pmc_mfma_pipe_utilisation': mfma_util, 'pmc_source': prof_src,
+                               'field_sources': {'measured_in_this_run': ['achieved', 'frac', 'avg_launch_ms', 'launches', 'isolated_tflops',
+                                                                          'isolated_avg_launch_ms', 'flops_per_launch',
+                                                                          'algorithmic_bytes_per_launch'],
+                                                 'from_committed_rocprofv3_pmc_passes': ['traffic', 'pmc_mfma_pipe_utilisation'],
+                                                 'pmc_profile_of_this_library_build': prof_src is not None,
+                                                 'stale_profiles_ignored': [x for x in (stale_t, stale_m) if x]}}
             if dom.startswith('conv_wgrad'):
                 # one weight-gradient op = the split-K MFMA kernel + its fixed-order fp32 reduction (wgrad_reduce): the event
                 # bracket, avg_launch_ms and achieved cover BOTH; rocprofv3 lists them as two kernels (their averages add up)
@@ -503,6 +616,7 @@ def main():
                                'note': 'survey pass: all ops bracketed, one lane, untimed'}
             out['ms_per_step_by_kernel'] = {k: round(v['ms'] / 3, 3) for k, v in
                                             sorted(survey.items(), key=lambda kv: -kv[1]['ms'])}
+            out['layer_roofline'] = layer_roofline(eng, pl, 3)
             n = pl.step.n
             ms = (C.c_float * n)()
             if args.dump_ops:

@@ -644,6 +644,7 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_
     a.tilesN = cdiv(a.K, 64 * tn);
     // timing-only diagnostics (wrong results): a descriptor with zero records drops every load through it while the
     // instruction stream, the waits and the barriers stay -- what does one operand's traffic cost?
+#ifdef IFCBK_EXPERIMENT_DROP          // make EXTRA=-DIFCBK_EXPERIMENT_DROP: never in the shipped library (a stray variable must not corrupt results)
     if (const char* e = getenv("IFCBK_DEBUG_DROP")) {
         if (strchr(e, 'a')) a.xbytes = 0;
         if (strchr(e, 'b')) a.wbytes = 0;
@@ -653,6 +654,7 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* args, int mt, int tn, hipStream_
         if (strchr(e, 'e')) a.dbg |= 8;           // no epilogue
         if (strchr(e, 'f')) a.dbg |= 16;          // affine + ReLU on every pixel fragment after its LDS read
     }
+#endif
     if (mt == 8 && tn == 2) launch_big<2, 8>(a, st);
     else if (mt == 8 && tn == 3) launch_big<3, 8>(a, st);
     else if (mt == 8 && tn == 4) launch_big<4, 8>(a, st);

@@ -15,6 +15,16 @@ from . import _lib
 from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
+# environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
+_DISPATCH_SWITCHES = ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_BIG_NPH', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+                      'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
+                      'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_PP_DM', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
+
+
+def _dispatch_env():
+    return tuple(os.environ.get(k) for k in _DISPATCH_SWITCHES)
+
+
 def _vp(t, byte_off=0):
     return None if t is None else C.c_void_p(t.data_ptr() + byte_off)
 
@@ -645,7 +655,14 @@ class Engine:
         key = (N, self.in_slot)
         if key not in self._plans:
             self._plans[key] = self._build(N)
-        return self._plans[key]
+            self._plans[key].dispatch_env = _dispatch_env()
+        pl = self._plans[key]
+        if pl.dispatch_env != _dispatch_env():
+            # the library picks its conv kernels per launch from these switches, while the rows of the BatchNorm partial sums (and
+            # the workspace) were sized when the plan was built: a change in between would make bn_finalize sum the wrong rows
+            raise RuntimeError('a kernel-dispatch switch (%s) changed after the plan for batch %d was built: build a new model/engine '
+                               'instead' % (', '.join(k for k, v in zip(_DISPATCH_SWITCHES, pl.dispatch_env) if os.environ.get(k) != v), N))
+        return pl
 
     def _build(self, N):
         net = self.net

@@ -205,7 +205,11 @@ def load_pretrained_weights(backbone, path):
     standing in for the download ``pretrained=True`` triggers upstream (neuston_models.py:23-42).  As upstream, the
     classifier heads were replaced for ``num_o_classes`` AFTER the ImageNet weights were loaded: tensors whose shape differs
     (fc, AuxLogits.fc) keep their fresh initialisation.  Returns (loaded, skipped) key lists."""
-    sd = load_checkpoint_file(path)
+    try:
+        # a plain torchvision state_dict (the usual third-party download) needs no arbitrary unpickling
+        sd = torch.load(path, map_location='cpu', weights_only=True)
+    except Exception:
+        sd = load_checkpoint_file(path)        # a Lightning-style checkpoint holding one: the permissive loader of f-2
     if isinstance(sd, dict) and 'state_dict' in sd:
         sd = sd['state_dict']
     sd = {(k[len('model.'):] if k.startswith('model.') else k): v for k, v in sd.items()}

@@ -18,6 +18,22 @@ import sys
 from collections import defaultdict
 
 
+
+def build_id():
+    """which build of libifcbk.so these counters belong to: bench.py attaches them to a run only when the hash matches"""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get('IFCBK_LIB') or os.path.join(root, 'ifcb_classifier_amd', 'libifcbk.so')
+    sha = hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16] if os.path.exists(lib) else None
+    try:
+        head = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        head = None
+    return dict(lib_sha16=sha, git_head=head)
+
+
 def main():
     f = glob.glob('%s/*/*counter_collection.csv' % sys.argv[1])[0]
     per = defaultdict(lambda: defaultdict(float))      # (kernel, dispatch id) -> counter -> value
@@ -40,7 +56,7 @@ def main():
                       mfma_pipe_utilisation=busy / (cyc * 1024.0), mfma_mops_bf16_per_launch=mops / n)
     json.dump(dict(method='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE over `bench.py --steps 3 '
                           '--warmup 1 --no-cpu-baseline --no-events --train-only`; utilisation = busy / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)',
-                   kernels=out), open(sys.argv[2], 'w'), indent=1)
+                   kernels=out, **build_id()), open(sys.argv[2], 'w'), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]['mfma_busy_cycles_per_launch'] * kv[1]['launches'])[:14]:
         print('%-46s %5d launches  %9.0f cycles/launch  MFMA pipe %5.1f %%' % (k[:46], v['launches'], v['kernel_cycles_per_launch'],
                                                                                100 * v['mfma_pipe_utilisation']))

@@ -17,6 +17,22 @@ import sys
 from collections import defaultdict
 
 
+
+def build_id():
+    """which build of libifcbk.so these counters belong to: bench.py attaches them to a run only when the hash matches"""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get('IFCBK_LIB') or os.path.join(root, 'ifcb_classifier_amd', 'libifcbk.so')
+    sha = hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16] if os.path.exists(lib) else None
+    try:
+        head = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        head = None
+    return dict(lib_sha16=sha, git_head=head)
+
+
 def load(d, name):
     f = glob.glob('%s/*/*counter_collection.csv' % d)[0]
     agg = defaultdict(lambda: [0.0, 0])
@@ -38,7 +54,7 @@ def main():
         out[k] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wb, hbm_bytes_per_launch=rd + wb)
     json.dump(dict(method='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 '
                           '--warmup 1 --no-cpu-baseline --no-events`; KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read correction)',
-                   kernels=out), open(sys.argv[3], 'w'), indent=1)
+                   kernels=out, **build_id()), open(sys.argv[3], 'w'), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
         print('%-50s %6d launches  %8.1f MB/launch' % (k[:50], v['launches'], v['hbm_bytes_per_launch'] / 1e6))
 
