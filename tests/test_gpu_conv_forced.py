@@ -125,9 +125,8 @@ def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, 
     res = _bf(torch.randn(N, P, Q, K, generator=g))
     y2 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
     y2p, y2v = _slice(y2, ly // 2, K)
-    resd = res.to(torch.bfloat16).cuda()
-    ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scale.cuda()), _lib.ptr(shift.cuda()),
-             _lib.ptr(resd), K, 1, st)
+    resd, scd, shd = res.to(torch.bfloat16).cuda(), scale.cuda(), shift.cuda()     # (device copies stay referenced until the sync)
+    ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(resd), K, 1, st)
     torch.cuda.synchronize()
     want = torch.relu(_bf(yref) * scale + shift + res)          # the affine acts on the conv output as stored (rounded)
     assert _rel(y2v.float().cpu(), want) < 4e-3
@@ -155,9 +154,9 @@ def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, 
     part2 = torch.full((nrow, 2, Cc), float('nan'), device='cuda')
     dx3 = torch.full((N, H, W, LDX), float('nan'), dtype=torch.bfloat16, device='cuda')
     dx3p, dx3v = _slice(dx3, lx // 2, Cc)
-    rawd = raw.to(torch.bfloat16).cuda()
-    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx3p, _lib.ptr(rawd), Cc, _lib.ptr(mean.cuda()),
-             _lib.ptr(invstd.cuda()), _lib.ptr(bsc.cuda()), _lib.ptr(bsh.cuda()), _lib.ptr(part2), st)
+    rawd, dev = raw.to(torch.bfloat16).cuda(), [t.cuda() for t in (mean, invstd, bsc, bsh)]
+    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx3p, _lib.ptr(rawd), Cc, _lib.ptr(dev[0]), _lib.ptr(dev[1]),
+             _lib.ptr(dev[2]), _lib.ptr(dev[3]), _lib.ptr(part2), st)
     torch.cuda.synchronize()
     dxs = dx3v.float().cpu()
     assert torch.equal(dxs, first)
@@ -222,8 +221,8 @@ def test_wide_tile_producer_table_and_segmented_epilogues(ctx, forced):
     ks = (C.c_int32 * 3)(*ksegs)
     aff = (C.c_int32 * 3)(1, 0, 1)
     scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
-    ctx.call('ifcbk_conv2d_fwd_affine_segments', C.byref(d), _lib.ptr(xb), _lib.ptr(wk), 3, ptrs, ldys, ks, aff,
-             _lib.ptr(scale.cuda()), _lib.ptr(shift.cuda()), st)
+    scd, shd = scale.cuda(), shift.cuda()
+    ctx.call('ifcbk_conv2d_fwd_affine_segments', C.byref(d), _lib.ptr(xb), _lib.ptr(wk), 3, ptrs, ldys, ks, aff, _lib.ptr(scd), _lib.ptr(shd), st)
     torch.cuda.synchronize()
     yref = _bf(F.conv2d(x, w).permute(0, 2, 3, 1))
     act = torch.relu(yref * scale + shift)
@@ -319,7 +318,8 @@ def test_flat_image_kernel_forced(ctx, forced, case, lx, ly):
         scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
         y2 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
         y2p, y2v = _slice(y2, ly // 2, K)
-        ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scale.cuda()), _lib.ptr(shift.cuda()), None, 0, 1, st)
+        scd, shd = scale.cuda(), shift.cuda()
+        ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scd), _lib.ptr(shd), None, 0, 1, st)
         torch.cuda.synchronize()
         assert _rel(y2v.float().cpu(), torch.relu(_bf(yref) * scale + shift)) < 4e-3
     # ---- input gradient (the flat kernel in the swapped role: K -> C channels), plain and with the BN-backward sums (MODE 3)
@@ -342,8 +342,9 @@ def test_flat_image_kernel_forced(ctx, forced, case, lx, ly):
     part2 = torch.full((nrow, 2, Cc), float('nan'), device='cuda')
     dx3 = torch.full((N, H, W, LDX), float('nan'), dtype=torch.bfloat16, device='cuda')
     dx3p, dx3v = _slice(dx3, lx // 2, Cc)
-    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx3p, _lib.ptr(raw.to(torch.bfloat16).cuda()), Cc,
-             _lib.ptr(mean.cuda()), _lib.ptr(invstd.cuda()), _lib.ptr(bsc.cuda()), _lib.ptr(bsh.cuda()), _lib.ptr(part2), st)
+    rawd, dev = raw.to(torch.bfloat16).cuda(), [t.cuda() for t in (mean, invstd, bsc, bsh)]
+    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx3p, _lib.ptr(rawd), Cc, _lib.ptr(dev[0]), _lib.ptr(dev[1]),
+             _lib.ptr(dev[2]), _lib.ptr(dev[3]), _lib.ptr(part2), st)
     torch.cuda.synchronize()
     dxs = dx3v.float().cpu()
     assert torch.equal(dxs, first)
@@ -354,7 +355,7 @@ def test_flat_image_kernel_forced(ctx, forced, case, lx, ly):
     part3 = torch.full((nrow, 2, Cc), float('nan'), device='cuda')
     dx4 = torch.full((N, H, W, LDX), float('nan'), dtype=torch.bfloat16, device='cuda')
     dx4p, dx4v = _slice(dx4, lx // 2, Cc)
-    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx4p, _lib.ptr(raw.to(torch.bfloat16).cuda()), Cc,
-             _lib.ptr(mean.cuda()), _lib.ptr(invstd.cuda()), _lib.ptr(bsc.cuda()), _lib.ptr(bsh.cuda()), _lib.ptr(part3), st)
+    ctx.call('ifcbk_conv2d_dgrad_bnstat', C.byref(d), dyp, _lib.ptr(wT), dx4p, _lib.ptr(rawd), Cc, _lib.ptr(dev[0]), _lib.ptr(dev[1]),
+             _lib.ptr(dev[2]), _lib.ptr(dev[3]), _lib.ptr(part3), st)
     torch.cuda.synchronize()
     assert torch.equal(dx4v, dx3v) and torch.equal(part3, part2)
