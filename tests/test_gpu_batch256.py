@@ -74,7 +74,37 @@ def test_batch256_train_step_node_parity_with_production_dispatch():
             assert int(b.item()) == 1
 
 
-def test_batch256_eval_hipgraph_matches_oracle_on_a_subset():
+def test_resnet50_train_step_node_parity_at_the_batch_where_the_wide_tile_plans_fire():
+    """the conv dispatcher is shape-driven, not model-driven: at batch 256 resnet50's layer2 / layer3 convolutions (K = 256 ... 1024
+    output channels over 50,176 ... 200,704 pixels) are routed to the wide-tile kernels that inception_v3 tunes -- every node of
+    ONE training step against the oracle, with the dispatch asserted (reference: neuston_models.py:37-39, neuston_net.py:324)"""
+    from ifcb_classifier_amd.neuston_models import get_namebrand_model
+    torch.manual_seed(5)
+    Br, nc = 256, 7
+    hip = get_namebrand_model('resnet50', nc, max_batch=Br)
+    eng = hip.engine
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(Br, 3, 224, 224, generator=g)
+    y = torch.randint(0, nc, (Br,), generator=g)
+    hip.train()
+    loss = F.cross_entropy(hip(x.cuda()), y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item()
+    names = _kernels(eng, eng.plan(Br).step)
+    print('kernels of the resnet50 batch-256 step:', sorted(names))
+    for must in ('conv_pp2<', 'conv_wgrad_pp<'):
+        assert _has(names, must), (must, sorted(names))
+    worst = check_plan(hip, Br, None)
+    print('resnet50 batch-256 node-local worst rel errors:', {k: '%.2e' % v for k, v in worst.items()})
+    assert worst['raw'] < 3e-3 and worst['y'] < 3e-3 and worst['pool'] < 3e-3
+    assert worst['stats'] < 1e-4 and worst['head'] < 1e-4
+    assert worst['dW'] < 1e-2 and worst['dgamma'] < 1e-2 and worst['dbeta'] < 1e-2
+    assert worst['dx'] < 1.5e-2
+
+
+@pytest.mark.parametrize('B', [256, 768])        # 768: the batch the RUN headline is quoted at (bench.py run_mode)
+def test_batch256_eval_hipgraph_matches_oracle_on_a_subset(B):
     from ifcb_classifier_amd.neuston_models import get_namebrand_model
     from oracle import tv_models
     torch.manual_seed(3)
@@ -84,7 +114,7 @@ def test_batch256_eval_hipgraph_matches_oracle_on_a_subset():
     ora.load_state_dict({k: v.detach().cpu().clone() for k, v in hip.state_dict().items()}, strict=True)
     g = torch.Generator().manual_seed(4)
     x = torch.rand(B, 3, 299, 299, generator=g)
-    sub = [0, 1, 127, 128, 254, 255]
+    sub = [0, 1, B // 2 - 1, B // 2, B - 2, B - 1]
     # calibrate the running statistics on a few images (momentum 1) so that eval activations stay O(1)
     for m in ora.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -107,8 +137,8 @@ def test_batch256_eval_hipgraph_matches_oracle_on_a_subset():
         e32 = o32(x[sub])
     env = rel(eo, e32)
     r, r32 = rel(eh[sub], eo), rel(eh[sub], e32)
-    print('batch-256 eval logits (6 of 256 images): rel vs bf16-storage oracle %.3e, vs fp32 oracle %.3e, envelope %.3e'
-          % (r, r32, env))
+    print('batch-%d eval logits (6 of %d images): rel vs bf16-storage oracle %.3e, vs fp32 oracle %.3e, envelope %.3e'
+          % (B, B, r, r32, env))
     assert r < 0.5 * env + 2e-3 and r32 < 1.25 * env + 2e-3
     # an image's logits do not depend on its neighbours in the batch (fixed statistics): the same 6 images alone go through
     # the small-grid kernels (another summation order, the same envelope)
