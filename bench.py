@@ -148,7 +148,7 @@ def run_mode_leg(args, local):
     does not depend on the pixel values).  Batch sweep on 100 k ROIs each, then the full count at the best batch size."""
     from ifcb_classifier_amd import graph
     from ifcb_classifier_amd.engine import Engine
-    POOL, BMAX = 8192, 768
+    POOL, BMAX = 8192, 1024
     eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=BMAX)
     eng.init_weights(seed=1234)
     rois, _ = synth_rois(POOL + BMAX, 4321, eng.dev)
@@ -191,7 +191,7 @@ def run_mode_leg(args, local):
         return nb * B / dt, 1e3 * dt / nb, nb * B
 
     sweep = {}
-    for B in (256, 512, 768):
+    for B in (256, 512, 768, 1024):      # 1024: beyond the 776-image descriptor window of one launch (convolutions run as two image groups)
         ips, ms, n = run(B, 100000)
         sweep[str(B)] = dict(images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), rois=n)
     best = max(sweep, key=lambda b: sweep[b]['images_per_s'])
@@ -416,7 +416,7 @@ def main():
     # untimed survey pass: every op bracketed by HIP events, all ops back to back on ONE lane -> the per-kernel table
     # (each kernel alone on the GPU) and the dominant conv kernel.  Bracketing all ~530 ops costs ~1.6 ms per step, so the
     # timed region below brackets the dominant kernel only -- there on all lanes, i.e. as the step really runs.
-    survey, ev_dom, dom = None, None, None
+    survey, ev_dom, dom, layer_rf = None, None, None, None
     if do_survey:
         NS = 3
         ev_all = eng.plan(B).step.timed(single_lane=True)     # (the plan of the input slot the warm-up left current)
@@ -429,6 +429,7 @@ def main():
                 dist.broadcast(buf, 0)
             eng.params_changed()
         survey = op_table(NS)
+        layer_rf = layer_roofline(eng, pl, NS)            # (reads the survey's event slots: before the timed region reuses them)
         conv = {k: v for k, v in survey.items() if k.startswith('conv_')}
         # dominant kernel = the conv kernel instantiation (the name rocprofv3 lists) with the most time per step
         dom = max(conv, key=lambda k: conv[k]['ms'])
@@ -616,7 +617,7 @@ def main():
                                'note': 'survey pass: all ops bracketed, one lane, untimed'}
             out['ms_per_step_by_kernel'] = {k: round(v['ms'] / 3, 3) for k, v in
                                             sorted(survey.items(), key=lambda kv: -kv[1]['ms'])}
-            out['layer_roofline'] = layer_roofline(eng, pl, 3)
+            out['layer_roofline'] = layer_rf
             n = pl.step.n
             ms = (C.c_float * n)()
             if args.dump_ops:

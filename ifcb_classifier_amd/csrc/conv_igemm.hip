@@ -689,6 +689,35 @@ extern "C" int ifcbk_conv2d_fwd_affine(ifcbk_ctx* ctx, const ifcbk_conv_desc* d,
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
                          const FwdSegs* seg) {
+    if (d && (d->dtype == IFCBK_BF16 || d->dtype == IFCBK_F32) && d->N > 1) {
+        // The kernels address a tensor through a 32-bit buffer descriptor (2 GiB).  A forward WITHOUT batch statistics (eval /
+        // affine epilogues: every image on its own) whose tensors exceed the window runs as several launches over image groups
+        // -- same bits as one launch; a training forward (bn_part) cannot be cut: its statistics are per launch (check_desc fails)
+        const int64_t es = dtype_esize(d->dtype);
+        int64_t per = (int64_t)d->H * d->W * d->ldx * es;
+        const int64_t ypix = (int64_t)d->P * d->Q;
+        if (seg) { for (int q = 0; q < seg->n; ++q) per = per > ypix * seg->ld[q] * es ? per : ypix * seg->ld[q] * es; }
+        else per = per > ypix * d->ldy * es ? per : ypix * d->ldy * es;
+        if (residual) per = per > ypix * ldr * es ? per : ypix * ldr * es;
+        const int64_t G = per > 0 ? ((1ll << 31) - 1) / per : d->N;
+        if (d->N > G && G >= 1 && !bn_part) {
+            for (int64_t g0 = 0; g0 < d->N; g0 += G) {
+                ifcbk_conv_desc dd = *d;
+                dd.N = (int)(d->N - g0 < G ? d->N - g0 : G);
+                FwdSegs sg;
+                if (seg) {
+                    sg = *seg;
+                    for (int q = 0; q < seg->n; ++q) sg.y[q] = (char*)seg->y[q] + g0 * ypix * seg->ld[q] * es;
+                }
+                const int e = conv_fwd_impl(ctx, &dd, (const char*)x + g0 * d->H * d->W * d->ldx * es, w,
+                                            seg ? sg.y[0] : (y ? (char*)y + g0 * ypix * d->ldy * es : nullptr), nullptr, scale, shift,
+                                            residual ? (const char*)residual + g0 * ypix * ldr * es : nullptr, ldr, relu, stream,
+                                            seg ? &sg : nullptr);
+                if (e) return e;
+            }
+            return 0;
+        }
+    }
     if (int e = check_desc(ctx, d)) return e;
     if (fwd_rows(d) && !residual && !seg)
         return ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,

@@ -180,12 +180,15 @@ class Engine:
             self.dev = torch.device('cuda', device)
             torch.cuda.set_device(self.dev)
             self.ctx = _lib.Context(device)
-        # the kernels address every tensor through a 32-bit buffer descriptor (2 GiB window): the largest per-image tensor
-        # (inception_v3: 147x147x64 bf16 = 2.77 MB) bounds the images one launch can take (776 in bf16, 388 in fp32)
+        # The conv kernels address every tensor through a 32-bit buffer descriptor (2 GiB window): the largest per-image tensor
+        # (inception_v3: 147x147x64 bf16 = 2.77 MB) bounds the images ONE LAUNCH can take (776 in bf16, 388 in fp32).  Programs
+        # without batch statistics (the eval forward) go beyond it: the library cuts such a convolution into launches over image
+        # groups (csrc/conv_igemm.hip conv_fwd_impl), so the engine's capacity is what was asked for; a TRAINING step beyond the
+        # window is refused (BatchNorm statistics and the split-K weight gradient are per launch).
         self.requested_batch = int(max_batch)
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
         self.window_batch = max(1, ((1 << 31) - 1) // per_img)
-        self.max_batch = min(int(max_batch), self.window_batch)
+        self.max_batch = int(max_batch)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.packed = False
@@ -1317,6 +1320,7 @@ class Engine:
     def train_step_ddp(self, N, world, all_reduce):
         """data-parallel step: gradient all-reduce (sum) of each finished tail bucket is launched right after
         the backward segment that completes it and overlaps the remaining backward; Adam divides by world."""
+        self._check_train_batch(N)
         pl = self.plan(N)
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
@@ -1424,7 +1428,14 @@ class Engine:
                               self.dropout_seed + 0x9E3779B1 * (k + 1), self.dropout_calls * (1 << 26), self.stream())
         self.dropout_calls += 1
 
+    def _check_train_batch(self, N):
+        if N > self.window_batch:
+            raise RuntimeError('batch %d > %d: the 2 GiB buffer-descriptor window holds %d images of this network per launch, and '
+                               'BatchNorm batch statistics cannot be taken over chunks: use a smaller --batch per GPU (more GPUs)'
+                               % (N, self.window_batch, self.window_batch))
+
     def forward_train(self, N):
+        self._check_train_batch(N)
         pl = self.plan(N)
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
@@ -1463,6 +1474,7 @@ class Engine:
 
     def train_step(self, N, op_ms=None, ev_slot=None, ev_arr=None):
         """one fused launch list: fwd + CE(+0.4 aux) + bwd + Adam + weight repack; loss stays on device."""
+        self._check_train_batch(N)
         pl = self.plan(N)
         self.ensure_packed(pl)
         self.make_dropout_mask(N)

@@ -125,13 +125,13 @@ class HipBackbone(nn.Module):
     def forward(self, x):
         eng = self.engine
         if x.shape[0] > eng.max_batch:
-            if self.training or x.shape[0] > eng.requested_batch:
-                why = ('the 2 GiB buffer-descriptor window holds %d images of this network per launch, and BatchNorm batch '
-                       'statistics cannot be taken over chunks: use a smaller --batch per GPU (more GPUs)' % eng.window_batch
-                       if x.shape[0] <= eng.requested_batch else 'construct with a larger max_batch')
-                raise RuntimeError('batch %d > capacity %d: %s' % (x.shape[0], eng.max_batch, why))
-            # eval mode: samples are independent, so a batch beyond the descriptor window runs as chunks (same results)
-            return torch.cat([self.forward(c) for c in x.split(eng.max_batch)], 0)
+            raise RuntimeError('batch %d > capacity %d: construct with a larger max_batch' % (x.shape[0], eng.max_batch))
+        if self.training and x.shape[0] > eng.window_batch:
+            # (an EVAL batch beyond the window is one program all the same: the library cuts its convolutions into launches over
+            # image groups -- samples are independent)
+            raise RuntimeError('batch %d > %d: the 2 GiB buffer-descriptor window holds %d images of this network per launch, and BatchNorm '
+                               'batch statistics cannot be taken over chunks: use a smaller --batch per GPU (more GPUs)'
+                               % (x.shape[0], eng.window_batch, eng.window_batch))
         N = eng.load_input_nchw(x)
         if self.training:
             if torch.is_grad_enabled():

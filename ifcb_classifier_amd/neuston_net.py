@@ -293,7 +293,7 @@ def do_training(args):
         print('Loaded {} pretrained tensors from {}; freshly initialised: {}'.format(
             len(loaded), args.weights, [k for k in skipped if not k.endswith('num_batches_tracked')]))
     eng = classifier.model.engine
-    if eng.max_batch < args.batch_size:
+    if eng.window_batch < args.batch_size:
         # --batch is per GPU as upstream (neuston_net.py:102); BatchNorm statistics are per step, so a step cannot be chunked
         raise ValueError('--batch %d: one launch addresses each tensor through a 2 GiB buffer descriptor, which holds %d images '
                          'of %s; use --batch <= %d per GPU (and more GPUs for a larger global batch)'
@@ -328,11 +328,8 @@ def do_run(args):
     classifier = NeustonModel.load_from_checkpoint(args.MODEL, device=int(os.environ.get('LOCAL_RANK', 0)),
                                                    max_batch=args.batch_size)
     seed_everything(classifier.hparams.seed)
-    if classifier.model.engine.max_batch < args.batch_size:
-        # results are per image: a batch beyond the 2 GiB buffer-descriptor window is only a smaller launch, not a different answer
-        print('--batch %d exceeds the %d images one launch can address; running batches of %d'
-              % (args.batch_size, classifier.model.engine.window_batch, classifier.model.engine.max_batch))
-        args.batch_size = classifier.model.engine.max_batch
+    # (a RUN batch beyond the 2 GiB buffer-descriptor window needs nothing here: results are per image, and the library cuts the
+    #  convolutions of such a batch into launches over image groups)
     if os.path.isdir(args.SRC) and not args.SRC.endswith(os.sep):
         args.SRC = args.SRC + os.sep
     if not args.outfile:

@@ -320,27 +320,35 @@ def test_hipgraph_replay_equals_plain_launches(name, B, S, lanes, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_batch_beyond_the_descriptor_window_is_chunked_in_eval_and_refused_in_training():
-    """every tensor is addressed through a 32-bit buffer descriptor: the engine caps its capacity at the images that fit
-    2 GiB (776 for inception_v3 in bf16); an eval batch beyond it runs as chunks with identical results, a training
-    batch is refused (BatchNorm statistics are per step)."""
+def test_batch_beyond_the_descriptor_window_is_one_eval_program_and_refused_in_training():
+    """The conv kernels address a tensor through a 32-bit buffer descriptor: 776 inception_v3 images (bf16) fit the 2 GiB window of
+    ONE launch.  An eval batch beyond it (SURVEY 8(d) config 4 sweeps batch 1024) is still one program / one hipGraph: the library
+    cuts each convolution into launches over image groups, and the logits equal those of the same images run 256 at a time, bit
+    for bit (samples are independent: neuston_models.py:152-157).  A training batch beyond the window is refused (BatchNorm batch
+    statistics are per step)."""
     from ifcb_classifier_amd.neuston_models import get_namebrand_model
-    m = get_namebrand_model('resnet18', 3, max_batch=12)
+    B = 1024
+    torch.manual_seed(11)
+    m = get_namebrand_model('inception_v3', 12, max_batch=B)
     eng = m.engine
-    assert eng.window_batch == ((1 << 31) - 1) // (112 * 112 * 64 * 2) and eng.max_batch == 12
-    eng.window_batch, eng.max_batch = 5, 5              # pretend the window holds 5 images
-    x = torch.rand(12, 3, 224, 224).cuda()
+    assert eng.window_batch == ((1 << 31) - 1) // (147 * 147 * 64 * 2) == 776 and eng.max_batch == B
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(B, 3, 299, 299, generator=g).cuda()
     m.eval()
     with torch.no_grad():
-        whole = m(x)
-        parts = torch.cat([m(x[:5]), m(x[5:10]), m(x[10:])], 0)
-    assert whole.shape == (12, 3) and torch.equal(whole, parts)
+        m(x)                                   # captures the batch-1024 graph
+        whole = m(x)                           # replays it
+        parts = torch.cat([m(x[i:i + 256]) for i in range(0, B, 256)], 0)
+    assert 'fwd_eval' in eng.plan(B).graphs
+    assert whole.shape == (B, 12) and torch.isfinite(whole).all() and torch.equal(whole, parts)
     m.train()
     with pytest.raises(RuntimeError, match='BatchNorm batch statistics'):
         m(x)
+    with pytest.raises(RuntimeError, match='BatchNorm batch statistics'):
+        eng.train_step(B)
     with pytest.raises(RuntimeError, match='larger max_batch'):
         m.eval()
-        m(torch.rand(13, 3, 224, 224).cuda())
+        m(torch.rand(B + 1, 3, 299, 299).cuda())
 
 
 @pytest.mark.gpu
