@@ -527,15 +527,20 @@ class Engine:
         self.in_slot = slot
         self.act[self.net.input.id] = self.in_bufs[slot]
 
-    def prefetch_begin(self):
-        """-> (slot, stream): everything the caller enqueues on `stream` until prefetch_end() -- host-to-device copies of the
-        next batch, load_rois(..., slot=slot), the label copy into tgt_bufs[slot] -- runs beside the step in flight.  The side
-        stream first waits until the last step that read this slot has finished."""
+    def prefetch_stream(self):
+        """the side stream of the input pipeline (created on first use, with its own library context / workspace arena)"""
         if self.plan_only:
             raise RuntimeError('prefetch: this engine was built with plan_only=True')
         if self.pre_stream is None:
             self.pre_stream = torch.cuda.Stream(self.dev)
             self.pre_ctx = _lib.Context(self.dev.index)          # its own workspace arena: the resize tables of the prefetch
+        return self.pre_stream
+
+    def prefetch_begin(self):
+        """-> (slot, stream): everything the caller enqueues on `stream` until prefetch_end() -- host-to-device copies of the
+        next batch, load_rois(..., slot=slot), the label copy into tgt_bufs[slot] -- runs beside the step in flight.  The side
+        stream first waits until the last step that read this slot has finished."""
+        self.prefetch_stream()
         slot = 1 - self.in_slot
         if self.ev_free[slot] is not None:
             self.pre_stream.wait_event(self.ev_free[slot])

@@ -60,14 +60,18 @@ class Bin:
         self.pid = Pid(os.path.basename(basepath))
         self.schema = self.pid.schema
         self._images = None
+        self._table = None
+        self._blob = None
 
     @property
-    def images(self):
-        """{target_number: u8 [h,w]} -- all ROIs of the bin in RAM, as IfcbBinDataset expects (:446-454)."""
-        if self._images is None:
+    def table(self):
+        """the .adc read ONCE into parallel int arrays over the ROIs with an image (zero-area triggers carry none):
+        ``targets`` (1-based ADC row = target number), ``offs`` (byte offset of the ROI in the .roi file), ``hs``, ``ws``.
+        Together with ``blob`` this is the whole bin: ROI i is blob[offs[i] : offs[i] + hs[i]*ws[i]] as [hs[i], ws[i]] u8 --
+        the form ifcbk_roi_preprocess consumes (one upload per bin)."""
+        if self._table is None:
             cx = 9 if self.schema == SCHEMA_VERSION_1 else 13
-            out = {}
-            roi = np.fromfile(self.basepath + '.roi', dtype=np.uint8)
+            tg, of, hs, ws = [], [], [], []
             with open(self.basepath + '.adc') as f:
                 for n, line in enumerate(f, 1):
                     cols = line.strip().split(',')
@@ -76,8 +80,28 @@ class Bin:
                     w, h, start = int(float(cols[cx + 2])), int(float(cols[cx + 3])), int(float(cols[cx + 4]))
                     if w * h == 0:
                         continue
-                    out[n] = roi[start:start + w * h].reshape(h, w)
-            self._images = out
+                    tg.append(n); of.append(start); hs.append(h); ws.append(w)
+            self._table = dict(targets=np.asarray(tg, dtype=np.int64), offs=np.asarray(of, dtype=np.int64),
+                               hs=np.asarray(hs, dtype=np.int32), ws=np.asarray(ws, dtype=np.int32))
+            size = os.path.getsize(self.basepath + '.roi')
+            t = self._table
+            if len(tg) and int((t['offs'] + t['hs'].astype(np.int64) * t['ws']).max()) > size:
+                raise ValueError('%s: an ADC row points past the end of the .roi file (%d bytes)' % (self.basepath, size))
+        return self._table
+
+    @property
+    def blob(self):
+        """the .roi file as one u8 array (read once)"""
+        if self._blob is None:
+            self._blob = np.fromfile(self.basepath + '.roi', dtype=np.uint8)
+        return self._blob
+
+    @property
+    def images(self):
+        """{target_number: u8 [h,w]} -- all ROIs of the bin in RAM, as IfcbBinDataset expects (:446-454): views into ``blob``."""
+        if self._images is None:
+            t, roi = self.table, self.blob
+            self._images = {int(n): roi[o:o + h * w].reshape(h, w) for n, o, h, w in zip(t['targets'], t['offs'], t['hs'], t['ws'])}
         return self._images
 
     def __len__(self):

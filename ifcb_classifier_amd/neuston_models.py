@@ -316,6 +316,35 @@ class NeustonModel(nn.Module):
         eng.prefetch_end(slot)
         return n
 
+    def stage_resident(self, res, i0, i1, transform=None):
+        """stage ROIs i0..i1-1 of a bin whose .roi blob and ADC table already live on the device (``res`` from
+        ``upload_bin``): the preprocess kernel reads them where they are -- no per-batch slicing, concatenation or upload"""
+        eng = self.model.engine
+        slot, side = eng.prefetch_begin()
+        with torch.cuda.stream(side):
+            side.wait_event(res['ready'])
+            kw = dict(pixels=res['pixels'], offs=res['offs'][i0:i1], hs=res['hs'][i0:i1], ws=res['ws'][i0:i1],
+                      max_h=res['max_h'], max_w=res['max_w'], in_channels=1)
+            if transform is not None and transform.img_norm is not None:
+                kw['mean'], kw['std'] = transform.img_norm
+            n = eng.load_rois(slot=slot, **kw)
+        eng.prefetch_end(slot)
+        return n
+
+    def upload_bin(self, blob, offs, hs, ws):
+        """one upload per bin: the raw .roi bytes and the offset / size table of its ROIs"""
+        eng = self.model.engine
+        slot_stream = eng.prefetch_stream()
+        with torch.cuda.stream(slot_stream):
+            host = torch.from_numpy(blob).pin_memory()
+            res = dict(host=host, pixels=host.to(eng.dev, non_blocking=True),      # (the pinned copy lives as long as the bin's batches)
+                       offs=torch.from_numpy(offs).to(eng.dev, non_blocking=True),
+                       hs=torch.from_numpy(hs).to(eng.dev, non_blocking=True), ws=torch.from_numpy(ws).to(eng.dev, non_blocking=True),
+                       max_h=int(hs.max()), max_w=int(ws.max()))
+            res['ready'] = torch.cuda.Event()
+            res['ready'].record(slot_stream)
+        return res
+
     def use_staged(self):
         self.model.engine.use_prefetched()
 

@@ -208,6 +208,30 @@ class Trainer:
             written += cb.on_test_end(rr, model)
         return rr, written
 
+    def test_resident(self, model, bin_fileset, ds, input_obj, callbacks, batch_size):
+        """RUN on one raw bin the way SURVEY 8 f-3 means it (reference data path: neuston_data.py:433-467, one PIL image per
+        ROI through DataLoader workers): the .adc was read ONCE into an offset / size table, the .roi blob is uploaded ONCE, and
+        every batch of the bin is preprocessed on the GPU straight from that resident blob (ifcbk_roi_preprocess takes absolute
+        byte offsets) -- no per-ROI slicing, no per-batch concatenation or upload.  Same scores as ``test`` over a DataLoader of
+        the bin, bit for bit."""
+        t = bin_fileset.table
+        res = model.upload_bin(bin_fileset.blob, t['offs'], t['hs'], t['ws'])
+        n_total = len(t['targets'])
+        bounds = [(i, min(i + batch_size, n_total)) for i in range(0, n_total, batch_size)]
+        steps, n_next = [], None
+        for k, (i0, i1) in enumerate(bounds):
+            n = model.stage_resident(res, i0, i1, ds.transform) if n_next is None else n_next
+            model.use_staged()
+            n_next = model.stage_resident(res, bounds[k + 1][0], bounds[k + 1][1], ds.transform) if k + 1 < len(bounds) else None
+            probs, _ = model.eval_current(n)
+            steps.append(dict(test_outputs=probs, test_srcs=list(ds.pids[i0:i1])))
+        rr = model.test_epoch_end(steps, input_obj)
+        rr.type = 'Bin'
+        written = []
+        for cb in callbacks:
+            written += cb.on_test_end(rr, model)
+        return rr, written
+
     def test_many(self, model, bins, batch_size, num_workers, callbacks):
         """--gobig: classify the ROIs of all ``bins`` [(pid, IfcbBinDataset)] as one stream of full batches, then write one
         result set per bin (the per-bin files are the same as without --gobig: an image's scores do not depend on its batch)."""
@@ -395,6 +419,10 @@ def do_run(args):
                 if args.gobig:
                     print('.', end='', flush=True)
                     big.append((bin_obj, ds))
+                    continue
+                if hasattr(bin_fileset, 'table') and hasattr(bin_fileset, 'blob') and os.environ.get('IFCBK_BIN_RESIDENT', '1') != '0':
+                    # one upload per bin, batches cut on the device (f-3); IFCBK_BIN_RESIDENT=0: the per-ROI DataLoader path below
+                    trainer.test_resident(classifier, bin_fileset, ds, bin_obj, callbacks, args.batch_size)
                     continue
                 loader = DataLoader(ds, batch_size=args.batch_size, pin_memory=True, num_workers=args.loaders,
                                     collate_fn=collate_rois)

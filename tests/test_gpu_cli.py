@@ -100,6 +100,31 @@ def test_train_then_run_img_and_bin(tmp_path, capsys):
     capsys.readouterr()
     _cli(argv)
     assert 'already exist - skipping this bin' in capsys.readouterr().out
+    # ---- f-3: the default bin path above uploaded the .roi blob ONCE and cut the batches on the device from the ADC table
+    # (Trainer.test_resident); the per-ROI DataLoader path (the reference's shape, neuston_data.py:433-467) writes the same bits.
+    # pyifcb is absent: what an .adc column means is this build's reading of the file layout -- PARITY UNPINNED (ifcb_bins.py)
+    import ifcb_classifier_amd.neuston_net as nn_mod
+    calls = []
+    orig = nn_mod.Trainer.test_resident
+    nn_mod.Trainer.test_resident = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+    try:
+        os.environ['IFCBK_BIN_RESIDENT'] = '0'
+        argv0 = list(argv)
+        argv0[argv0.index('r2')] = 'r3'
+        _cli(argv0)
+        assert not calls
+        os.environ.pop('IFCBK_BIN_RESIDENT')
+        argv1 = list(argv)
+        argv1[argv1.index('r2')] = 'r4'
+        _cli(argv1)
+        assert calls
+    finally:
+        nn_mod.Trainer.test_resident = orig
+        os.environ.pop('IFCBK_BIN_RESIDENT', None)
+    b3 = json.load(open(os.path.join(run_out, 'r3', 'v3', 'smoke', 'D2013', 'D20130526', lid + '_class.json')))
+    b4 = json.load(open(os.path.join(run_out, 'r4', 'v3', 'smoke', 'D2013', 'D20130526', lid + '_class.json')))
+    assert b3['roi_numbers'] == b4['roi_numbers'] == bj['roi_numbers']
+    assert b3['output_scores'] == b4['output_scores'] == bj['output_scores'] and b3['output_classes'] == b4['output_classes']
 
 
 def test_ddp_step_world1_equals_fused_step():

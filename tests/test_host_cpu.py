@@ -111,3 +111,42 @@ def test_schema_v1_bins_are_refused_not_silently_unstitched(monkeypatch):
     b2 = types.SimpleNamespace(pid=Pid('D20130526T092352_IFCB013'), schema='v2', images={2: np.zeros((3, 4), np.uint8)})
     monkeypatch.delenv('IFCBK_ALLOW_UNSTITCHED_V1')
     assert len(IfcbBinDataset(b2, 299)) == 1
+
+
+def test_bin_table_is_one_pass_over_the_adc_and_views_into_one_blob(tmp_path):
+    """f-3 (reference neuston_data.py:433-454 through pyifcb -- absent, so the column meaning is PARITY UNPINNED): the .adc is
+    read once into (targets, offs, hs, ws), the .roi once into one u8 blob; ``images`` are views into that blob -- the form
+    ifcbk_roi_preprocess takes (absolute byte offsets), so a bin is ONE upload."""
+    import numpy as np
+    from ifcb_classifier_amd.ifcb_bins import Bin, DataDirectory
+    lid = 'D20130526T092352_IFCB013'
+    rng = np.random.default_rng(3)
+    blob, lines, off, want = b'', [], 0, {}
+    for k in range(9):
+        h, w = (int(v) for v in rng.integers(5, 40, 2))
+        if k in (2, 7):
+            h = w = 0                                   # triggers without an image
+        a = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        cols = ['0'] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(off)
+        lines.append(','.join(cols))
+        blob += a.tobytes()
+        off += h * w
+        if h * w:
+            want[k + 1] = a
+    (tmp_path / (lid + '.adc')).write_text('\n'.join(lines) + '\n')
+    (tmp_path / (lid + '.roi')).write_bytes(blob)
+    b = Bin(str(tmp_path / lid))
+    t = b.table
+    assert list(t['targets']) == sorted(want) and t['offs'].dtype == np.int64 and t['hs'].dtype == np.int32
+    assert b.blob.nbytes == len(blob)
+    for i, n in enumerate(t['targets']):
+        img = b.images[int(n)]
+        assert img.base is not None and np.shares_memory(img, b.blob)          # a view, not a copy
+        assert np.array_equal(img, want[int(n)])
+        assert np.array_equal(b.blob[t['offs'][i]:t['offs'][i] + t['hs'][i] * t['ws'][i]].reshape(t['hs'][i], t['ws'][i]), img)
+    assert [x.pid.lid for x in DataDirectory(str(tmp_path))] == [lid]
+    # an ADC row past the end of the .roi file is an error, not a silent short read
+    (tmp_path / (lid + '.roi')).write_bytes(blob[:-10])
+    with pytest.raises(ValueError, match='past the end'):
+        Bin(str(tmp_path / lid)).table
