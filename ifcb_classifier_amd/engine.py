@@ -447,16 +447,12 @@ class Engine:
             if b.name.endswith(':raw'):
                 continue
             self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
-        # program lanes (branch-parallel streams) of the training programs: 4 on a single GPU; 2 in a data-parallel job, where
-        # the collective's stream joins in and the runtime's default of 4 hardware queues per process must not be
-        # oversubscribed (a 2-rank rehearsal on one GPU ran 97 ms/step with 2 lanes and 1.3-6.5 s with 3-4)
-        dp = False
-        try:
-            import torch.distributed as dist
-            dp = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        except Exception:
-            pass
-        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2' if dp else '4'))))
+        # program lanes (branch-parallel streams) of the training programs: 4, data-parallel jobs included.  Round 1 pinned DP jobs
+        # to 2 lanes after a 2-rank rehearsal ON ONE GPU stalled with 3-4 (1.3-6.5 s/step): two processes' 5 streams each on one
+        # device's hardware queues.  Round 3 measured the DP step itself on the real backend (scripts/dp_lanes.py: ProcessGroupNCCL,
+        # world 1, batch 256, bucketed async all-reduces on RCCL's stream beside the lanes): 2 / 3 / 4 lanes = 25.57 / 24.15 /
+        # 23.98 ms (fused step: 24.78 / 23.64 / 23.50) -- no stall with one process per GPU, which is how DP jobs run.
+        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '4'))))
         self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (measured best)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
         # launch list (6.73 vs 6.85 ms); the train fwd+bwd graph is 4 % SLOWER (28.7 vs 27.6 ms per step: the graph's own
