@@ -2,6 +2,7 @@
 // Every access is a 16-byte chunk (8 bf16 or 4 fp32 channels), consecutive lanes on consecutive chunks; all
 // kernels are templated on the storage type T (bf16 performance mode / fp32 parity mode).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -413,21 +414,32 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_pool2x2_kernel(const T* x, int 
 
 // ---------------------------------------------------------------- backward
 // pass 1: per-row-tile partial sums of dz and dz*xhat.  block: 8 chunks x 32 rows in flight
-constexpr int BWD_ROWS = 1024;
+constexpr int BWD_ROWS = 1024;      // largest row tile (the engine reserves the workspace for 256-row tiles: bwd_rows() stays >= 256)
+// Rows per tile of the reduction pass: a tile is one block, and with 1024-row tiles a 17x17 layer (73,984 rows x 192 channels)
+// was 219 blocks of 256 threads on 256 CUs -- 4 waves per CU, two loads in flight per lane: 2.2 TB/s.  Smaller tiles where the
+// tensor is small: ~3,000 blocks or more, never below 256 rows (workspace), never above 1024 (the finalize pass reads the rows)
+static inline int bwd_rows(int64_t M, int cgroups) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("IFCBK_BN_BWD_ROWS"); force = e ? atoi(e) : 0; }
+    if (force >= 32) return force / 32 * 32;
+    int64_t r = M * cgroups / 3000;
+    r = (r + 31) / 32 * 32;
+    return (int)(r < 256 ? 256 : r > BWD_ROWS ? BWD_ROWS : r);
+}
 // MASK: 0 = no ReLU, 1 = ReLU mask read from y (residual case), 2 = ReLU mask recomputed as x*scale+shift > 0
 // (bit-identical to what bn_apply stored: same expression, the sign survives rounding) -- saves the y read
 template <class T, int MASK, bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
                                                              const float* mean, const float* invstd, const float* scale,
-                                                             const float* shift, float* part, int64_t M, int C, PoolGather pg) {
+                                                             const float* shift, float* part, int64_t M, int C, PoolGather pg, int rows) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;                    // channels per block
     __shared__ float red[4][2][CG];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cc = t & 7, r0 = t >> 3;
     const int c = blockIdx.y * CG + cc * E;
-    const int64_t mbeg = (int64_t)blockIdx.x * BWD_ROWS;
-    const int64_t mend = mbeg + BWD_ROWS < M ? mbeg + BWD_ROWS : M;
+    const int64_t mbeg = (int64_t)blockIdx.x * rows;
+    const int64_t mend = mbeg + rows < M ? mbeg + rows : M;
     float sb[E], sg[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) sb[j] = sg[j] = 0.f;
@@ -621,7 +633,8 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     const int C = d->C;
     if (C % E || d->ldx % E || lddy % E || lddx % E) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: channels must be multiples of %d", E);
     const int64_t M = d->M;
-    int ntiles = cdiv(M, BWD_ROWS);
+    const int rows = bwd_rows(M, cdiv(C, CG));
+    int ntiles = cdiv(M, rows);
     size_t need = ((size_t)ntiles * 2 * C + 2 * C) * sizeof(float);
     if (need > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd: workspace %zu > reserved %zu", need, ctx->ws_bytes);
     float* part = (float*)ctx->ws;
@@ -663,11 +676,11 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         if ((size_t)2 * C * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_partials: workspace");
     } else if (pool) {
         if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
-        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
-    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg);
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
