@@ -343,6 +343,7 @@ def main():
         eng.params_changed()
     rois, _ = synth_rois(B, 1234 + rank, eng.dev)
     eng.target[:B].copy_(torch.randint(0, args.classes, (B,), generator=torch.Generator().manual_seed(99 + rank)))
+    eng.load_rois(**rois)          # (the plan is per input kind: grey ROIs arrive as the resized u8 plane)
     pl = eng.plan(B)
     do_survey = (not args.no_events) and args.steps <= 256
     use_ev = do_survey and world == 1        # events in the timed region: single-GPU runs only (the N>1 step is several programs)

@@ -121,6 +121,11 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                            (int)o->i[0], (o->flags >> 2) & 1, st);
         case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
         case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
+        case IFCBK_OP_STEM_U8_FWD:
+            return ifcbk_stem_u8_fwd(c, &o->u.conv, (const uint8_t*)p[0], (const float*)p[1], (const float*)p[2], p[3], (float*)p[4],
+                                     (const float*)p[5], (const float*)p[6], (o->flags >> 2) & 1, st);
+        case IFCBK_OP_STEM_U8_WGRAD:
+            return ifcbk_stem_u8_wgrad(c, &o->u.conv, (const uint8_t*)p[0], p[1], (const float*)p[2], (float*)p[3], acc, st);
         case IFCBK_OP_CONV_WGRAD_SEG: {
             float* dws[4];
             int32_t ks[4];
@@ -494,6 +499,8 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
             break;
         }
+        case IFCBK_OP_STEM_U8_FWD: snprintf(name, cap, "stem_u8_fwd_kernel"); break;
+        case IFCBK_OP_STEM_U8_WGRAD: snprintf(name, cap, "stem_u8_wgrad_kernel"); break;
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
         case IFCBK_OP_BN_BWD_PARTIALS: snprintf(name, cap, "bn_bwd(partials)"); break;
@@ -528,6 +535,12 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
                    wb = (double)d.K * d.R * d.S * d.C * 2;
             by = xin + yout + wb + ((o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? xin : 0);      // + one read of the producer's raw output
+            break;
+        }
+        case IFCBK_OP_STEM_U8_FWD: case IFCBK_OP_STEM_U8_WGRAD: {
+            const ifcbk_conv_desc& d = o->u.conv;      // the conv's own MACs (3 input channels); bytes: the u8 plane + the output / its gradient
+            fl = 2.0 * d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
+            by = (double)d.N * d.H * d.W + (double)d.N * d.P * d.Q * d.K * 2;
             break;
         }
         case IFCBK_OP_BN_APPLY: by = (double)o->u.bn.M * o->u.bn.C * (2 + 2 + (o->p[3] ? 2 : 0)); break;

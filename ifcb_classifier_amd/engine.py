@@ -493,6 +493,18 @@ class Engine:
         self.tgt_bufs = [torch.zeros(N, dtype=torch.int64, device=dev) for _ in range(2)]
         self.in_bufs = [self.act[net.input.id], torch.zeros_like(self.act[net.input.id])]
         self.in_slot = 0
+        # Grey ROIs into inception's Conv2d_1a: the resize writes only the u8 plane and the stem conv reads it directly
+        # (csrc/conv_stem_u8.hip) -- the [N,S,S,8] tensor of the slot is then not written at all.  in_kind[slot]: 'nhwc' (the dense
+        # tensor is current: load_input_nchw, RGB images) or 'u8' (the plane is current); programs are built per (slot, kind).
+        self.stem_u8 = None
+        first = [n for n in self.convs if n.x.buf.is_input]
+        if (os.environ.get('IFCBK_STEM_U8', '1') != '0' and len(first) == 1 and first[0].group is None
+                and self.ctx.lib.ifcbk_stem_u8_rows(C.byref(self._conv_desc(first[0], N))) > 0):
+            self.stem_u8 = first[0]
+            self.in_u8 = [torch.zeros(N, net.S, net.S, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.in_ab = [torch.zeros(6, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._in_ab_host = [None, None]
+        self.in_kind = ['nhwc', 'nhwc']
         self.pre_stream = self.pre_ctx = None
         self.ev_ready, self.ev_free, self.prefetched = [None, None], [None, None], None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -512,6 +524,8 @@ class Engine:
         for n in self.bnrs:
             M = N * n.x.H * n.x.W
             ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
+        if self.stem_u8 is not None:
+            ws = max(ws, self.ctx.lib.ifcbk_stem_u8_wgrad_workspace(C.byref(self._conv_desc(self.stem_u8, N))))
         self.ctx.reserve(ws)
 
     @property
@@ -656,7 +670,7 @@ class Engine:
     def plan(self, N):
         if N > self.max_batch:
             raise RuntimeError('batch %d exceeds the engine capacity %d' % (N, self.max_batch))
-        key = (N, self.in_slot)
+        key = (N, self.in_slot, self.in_kind[self.in_slot])
         if key not in self._plans:
             self._plans[key] = self._build(N)
             self._plans[key].dispatch_env = _dispatch_env()
@@ -820,6 +834,11 @@ class Engine:
                 wT = _vp(self.Wsh, self.esize * n.wT_off)
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 mb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
+                # the stem conv on the resized u8 plane of this slot (conv_stem_u8.hip) instead of the [N,S,S,8] tensor
+                u8 = self.stem_u8 is n and self.in_kind[self.in_slot] == 'u8'
+                if u8:
+                    mb = self.ctx.lib.ifcbk_stem_u8_rows(C.byref(d))
+                    gu8, gab = _vp(self.in_u8[self.in_slot]), _vp(self.in_ab[self.in_slot])
                 bnd = BnDesc(M, n.K, ldraw, n.y.buf.C, 1 if n.relu else 0, self.cdtype, n.eps, 0.1)
                 g = n.group
                 first_of_group = g is not None and g.members[0] is n
@@ -869,6 +888,11 @@ class Engine:
                         lst.add(_lib.OP_AVGPOOL_AFFINE, cp.name + '(' + n.name + ')',
                                 p=(pre, self._stat(n, 4), self._stat(n, 5), self._aptr(n.y)), flags=4 if n.relu else 0, pool=ppd,
                                 lane=Le, reads=[rpre], writes=[ra(n.y)])
+                        continue
+                    if not train and u8:
+                        lst.add(_lib.OP_STEM_U8_FWD, n.name,
+                                p=(gu8, self._pptr(ckey), gab, self._aptr(n.y), None, self._stat(n, 4), self._stat(n, 5)),
+                                flags=4 if n.relu else 0, conv=d, lane=Le, reads=[ra(n.x)], writes=[ra(n.y)])
                         continue
                     if not train:
                         # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
@@ -920,8 +944,12 @@ class Engine:
                                     p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd,
                                     lane=lane_of[m], reads=[rraw(m), rst(m)], writes=[ra(m.y)])
                         continue
-                    lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part[L]) if train else None),
-                            conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
+                    if u8:
+                        lst.add(_lib.OP_STEM_U8_FWD, n.name, p=(gu8, self._pptr(ckey), gab, raw, _vp(self.bn_part[L]), None, None),
+                                conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
+                    else:
+                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part[L]) if train else None),
+                                conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
                     if train:
                         lst.add(_lib.OP_BN_FINALIZE, n.name,
                                 p=(_vp(self.bn_part[L]), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
@@ -1185,9 +1213,14 @@ class Engine:
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
                 # wgrad and dgrad only share their input d(raw); IFCBK_WGRAD_SIDE=1 puts the weight gradient on the neighbouring
                 # lane -- measured slower (31.5 vs 29.1 ms/step): the next node's bn_bwd must wait for it to release the scratch
-                bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
-                        lane=(L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L,
-                        reads=[ra(n.x)] + rdraw, writes=[])
+                if self.stem_u8 is n and self.in_kind[self.in_slot] == 'u8':
+                    bwd.add(_lib.OP_STEM_U8_WGRAD, n.name,
+                            p=(_vp(self.in_u8[self.in_slot]), draw, _vp(self.in_ab[self.in_slot]), self._pptr(ckey, 'G')), conv=dbw,
+                            lane=L, reads=[ra(n.x)] + rdraw, writes=[])
+                else:
+                    bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
+                            lane=(L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L,
+                            reads=[ra(n.x)] + rdraw, writes=[])
                 if needs_dgrad:
                     assert n.x.is_full
                     acc = acc_flag(n.x.buf)
@@ -1288,6 +1321,8 @@ class Engine:
         base = self.G.data_ptr()
         if o.kind == _lib.OP_CONV_WGRAD:
             return [(o.p[2] - base) // 4]
+        if o.kind == _lib.OP_STEM_U8_WGRAD:
+            return [(o.p[3] - base) // 4]
         if o.kind == _lib.OP_CONV_WGRAD_SEG:
             return [(o.p[2 + k] - base) // 4 for k in range(4) if o.i[k] > 0]
         # (a vgg*_bn conv's bias rides with its BatchNorm's gradients: nothing writes it -- the batch mean absorbs the bias, its
@@ -1370,19 +1405,21 @@ class Engine:
             sh = (C.c_float * 3)((0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5)
         self.ctx.call('ifcbk_nchw_to_nhwc', _vp(x), N, 3, S, S, 8, self.cdtype, sc, sh, _vp(self.act[self.net.input.id]),
                       self.stream())
+        self.in_kind[self.in_slot] = 'nhwc'
         return N
 
     def load_rois(self, pixels, offs, hs, ws, max_h, max_w, in_channels=1, flips=None, mean=None, std=None, slot=None):
         """ragged u8 ROIs (device tensors) -> input buffer via the PIL-exact resize kernel.  slot: the input slot of a
         prefetch (runs on the prefetch stream with the prefetch context's workspace); None = the current slot, current stream."""
         if slot is not None:
-            return self._load_rois_into(self.pre_ctx, C.c_void_p(self.pre_stream.cuda_stream), self.in_bufs[slot], False,
+            return self._load_rois_into(self.pre_ctx, C.c_void_p(self.pre_stream.cuda_stream), slot, False,
                                         pixels, offs, hs, ws, max_h, max_w, in_channels, flips, mean, std)
-        return self._load_rois_into(self.ctx, self.stream(), self.act[self.net.input.id], True, pixels, offs, hs, ws, max_h,
+        return self._load_rois_into(self.ctx, self.stream(), self.in_slot, True, pixels, offs, hs, ws, max_h,
                                     max_w, in_channels, flips, mean, std)
 
-    def _load_rois_into(self, ctx, stream, dst, main, pixels, offs, hs, ws, max_h, max_w, in_channels, flips, mean, std):
+    def _load_rois_into(self, ctx, stream, slot, main, pixels, offs, hs, ws, max_h, max_w, in_channels, flips, mean, std):
         n = hs.numel()
+        dst = self.in_bufs[slot]
         d = RoiDesc()
         d.n_img, d.S, d.in_channels, d.out_channels = n, self.net.S, in_channels, 8
         d.flip_bits_valid = 1 if flips is not None else 0
@@ -1404,8 +1441,22 @@ class Engine:
                     for g in pl.graphs.values():
                         self.ctx.lib.ifcbk_graph_destroy(self.ctx.h, g)
                     pl.graphs.clear()
+        if self.stem_u8 is not None and in_channels == 1:
+            # grey ROIs: only the resized u8 plane is written; x_c = a_c * g + b_c (ToTensor, Normalize, transform_input) goes to the
+            # stem conv as six floats
+            ab = tuple(d.tin_scale[k] / (255.0 * d.std[k]) for k in range(3)) + \
+                tuple(d.tin_shift[k] - d.tin_scale[k] * d.mean[k] / d.std[k] for k in range(3))
+            if self._in_ab_host[slot] != ab:
+                with torch.cuda.stream(torch.cuda.current_stream(self.dev) if main else self.pre_stream):
+                    self.in_ab[slot].copy_(torch.tensor(ab, dtype=torch.float32), non_blocking=False)
+                self._in_ab_host[slot] = ab
+            ctx.call('ifcbk_roi_preprocess', C.byref(d), _vp(pixels), _vp(offs), _vp(hs), _vp(ws), _vp(flips),
+                     int(max_h), int(max_w), None, _vp(self.in_u8[slot]), stream)
+            self.in_kind[slot] = 'u8'
+            return n
         ctx.call('ifcbk_roi_preprocess', C.byref(d), _vp(pixels), _vp(offs), _vp(hs), _vp(ws), _vp(flips),
                  int(max_h), int(max_w), _vp(dst), None, stream)
+        self.in_kind[slot] = 'nhwc'
         return n
 
     def make_dropout_mask(self, N):

@@ -210,11 +210,31 @@ typedef struct {
     float   mean[3], std[3]; /* Normalize; std = 1, mean = 0 for none                                 */
     float   tin_scale[3], tin_shift[3]; /* [TV] transform_input affine (1,0 when off)                 */
 } ifcbk_roi_desc;
-/* pixels: concatenated u8 ROIs; offs[i] byte offset, hs[i]/ws[i] dims; out: [n_img,S,S,out_channels]  */
+/* pixels: concatenated u8 ROIs; offs[i] byte offset, hs[i]/ws[i] dims; out (nullable when out_u8 is given):
+ * [n_img,S,S,out_channels]                                                                             */
 int ifcbk_roi_preprocess(ifcbk_ctx*, const ifcbk_roi_desc*, const uint8_t* pixels, const int64_t* offs,
                          const int32_t* hs, const int32_t* ws, const uint8_t* flips, int max_h, int max_w,
                          void* out, uint8_t* out_u8 /*nullable: resized u8 [n,S,S,in_channels]*/, void* stream);
 size_t ifcbk_roi_preprocess_workspace(const ifcbk_roi_desc*, int max_h, int max_w);
+/* The stem conv straight from the resized u8 plane (grey ROIs: in_channels = 1).  convert('RGB') + ToTensor + Normalize
+ * (+ [TV] transform_input) make three copies of one plane g under per-channel affines x_c = ab[c] * g + ab[3 + c]; the
+ * 3x3 / stride-2 / unpadded / 32-channel Conv2d_1a of those is a one-plane conv plus a constant, so the [N,S,S,8] input
+ * tensor is never written: g = out_u8 of ifcbk_roi_preprocess ([N][H][W] bytes), w_master = the fp32 master filter
+ * [32][3][3][3], ab = 6 floats in device memory.  fp32 arithmetic on exact pixels and master weights; y rounded to d->dtype.
+ *   scale == shift == NULL: y = raw conv output, bn_part (nullable) [ifcbk_stem_u8_rows][2][32] partial sums of the rounded
+ *   outputs for ifcbk_bn_finalize;  otherwise y = act(conv * scale[k] + shift[k]) (eval-mode folded BatchNorm, relu flag).
+ * d: N, H, W of the plane, K = 32, R = S = 3, stride 2, pad 0, P, Q, ldy, Cw = 3 (C / ldx ignored); anything else:
+ * IFCBK_EUNSUPPORTED (ifcbk_stem_u8_rows returns 0) and the caller uses ifcbk_conv2d_* on the [N,S,S,8] tensor.
+ * wgrad: dw[k][r][s][c] (+)= ab[c] * sum dy[k] g[r,s] + ab[3 + c] * sum dy[k]; deterministic (per-block partials in the ctx
+ * workspace, fixed-order fp64 reduce).  dy: [N*P*Q] rows of 32, row stride d->ldy.
+ * Replaces aten::conv2d forward / weight gradient of [TV] Inception3.Conv2d_1a_3x3 on the output of the transform chain
+ * neuston_data.py:342-371, :456-464 (reference call sites neuston_models.py:66-68, 81-86).                               */
+int ifcbk_stem_u8_rows(const ifcbk_conv_desc*);
+int ifcbk_stem_u8_fwd(ifcbk_ctx*, const ifcbk_conv_desc* d, const uint8_t* g, const float* w_master, const float* ab, void* y,
+                      float* bn_part, const float* scale, const float* shift, int relu, void* stream);
+size_t ifcbk_stem_u8_wgrad_workspace(const ifcbk_conv_desc*);
+int ifcbk_stem_u8_wgrad(ifcbk_ctx*, const ifcbk_conv_desc* d, const uint8_t* g, const void* dy, const float* ab, float* dw,
+                        int accumulate, void* stream);
 /* fp32 NCHW [N,3,H,W] -> NHWC [N,H,W,Cpad] (zero padded), optional per-channel affine (transform_input) */
 int ifcbk_nchw_to_nhwc(ifcbk_ctx*, const float* x, int N, int C, int H, int W, int Cpad, int dtype,
                        const float* scale3, const float* shift3, void* y, void* stream);
@@ -321,7 +341,9 @@ enum {
     IFCBK_OP_CONV_DGRAD_BNSTAT_TAB,  /* p: dy, wT, dx, table, part (ifcbk_conv2d_dgrad_bnstat_table)                           */
     IFCBK_OP_BIAS_RELU_BWD,  /* p: y, dy, dz, dbias; u.bn: M, C, ldx = ld(y), ldy = ld(dy), relu, dtype; i[0] = ld(dz)          */
     IFCBK_OP_DROPOUT,        /* p: x, mask (nullable), y; i[0] = n, i[1] = dtype; f[0] = scale; flags bit 0 accumulate           */
-    IFCBK_OP_FLATTEN_CHW     /* p: x, flat; i: N, HW, C, ldx | dtype << 32; flags bit 0 accumulate, bit 2 to_chw                 */
+    IFCBK_OP_FLATTEN_CHW,    /* p: x, flat; i: N, HW, C, ldx | dtype << 32; flags bit 0 accumulate, bit 2 to_chw                 */
+    IFCBK_OP_STEM_U8_FWD,    /* p: g, w_master, ab, y, bn_part (nullable), scale, shift (both NULL: raw + statistics); flags bit 2 relu */
+    IFCBK_OP_STEM_U8_WGRAD   /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
 };
 typedef struct {
     int32_t kind;
