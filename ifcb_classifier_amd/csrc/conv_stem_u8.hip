@@ -13,6 +13,7 @@
 // to the storage type; BatchNorm partial sums over the rounded outputs like every other conv epilogue.
 // Replaces aten::conv2d fwd / weight-grad of [TV] Inception3.Conv2d_1a_3x3 (reference call site neuston_models.py:66-68, 81-86).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,7 +32,17 @@ struct StemArgs {
     int relu, H, W, P, Q, ld;
     unsigned M, PQ;
     fastdiv_t dPQ, dQ;
+    unsigned rows, gpr;        // MFMA kernels: output rows N*P, 32-pixel groups per output row
+    fastdiv_t dP, dG;
+#ifdef IFCBK_EXPERIMENT_STEM
+    int dbg;                   // timing-only builds: 1 no pixel loads, 2 no stores, 4 no statistics
+#endif
 };
+#ifdef IFCBK_EXPERIMENT_STEM
+#define STEM_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define STEM_DBG(a, bit) 0
+#endif
 
 template <class T> __device__ __forceinline__ void store8(T* p, const float* f);
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
@@ -200,6 +211,223 @@ __global__ __launch_bounds__(256) void stem_u8_wgrad_kernel(StemArgs a) {
         a.part[(size_t)blockIdx.x * (K1 * 10) + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
+// ---------------------------------------------------------------- bf16 storage: the same two passes on the matrix cores
+// As vector FMAs the forward was VALU-bound (125 instructions per 16 pixels and wave: 152 us for a tensor a fill writes in 62 us), the
+// weight gradient likewise (213 us).  Both are small GEMMs whose bf16 operands are EXACT: pixels 0..255 and dy are bf16 values, and the
+// fp32 effective taps go in as three bf16 pieces (hi + mid + lo = the fp32 value to 2^-24), each piece against its own copy of the pixel:
+//   forward   D[pixel][ch] = sum_k G[pixel][k] * Wsplit[k][ch],  k = 27 (tap, piece) slots + 3 bias pieces against a constant 1 + 2 zeros
+//             = two v_mfma_f32_32x32x16_bf16 per 32 pixels; a lane ends up with ONE channel of 16 pixels -> 32 lanes store a pixel's 64 bytes
+//   wgrad     D[ch][tap] = sum_pixels dy[pixel][ch] * G[pixel][tap], taps 0..8 + a constant-1 column (the sum of dy) = two
+//             v_mfma_f32_16x16x32_bf16 per 32 pixels (channels 0..15 / 16..31)
+// Work unit of a wave: 32 consecutive pixels of one output row (the last group of a row is partly masked); a block owns RB output rows.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int RB = 8;
+
+__device__ __forceinline__ unsigned bfbits(float f) { return __float_as_uint(f) >> 16; }           // exact for the values used here
+__device__ __forceinline__ unsigned bfpair(unsigned lo, unsigned hi) { return lo | (hi << 16); }
+// w = hi + mid + lo with bf16 pieces (round-to-nearest each; the remainders are exact in fp32)
+__device__ __forceinline__ void split3(float w, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = f2bf(w);
+    const float r1 = w - bf2f((bf16_t)hi);
+    mid = f2bf(r1);
+    lo = f2bf(r1 - bf2f((bf16_t)mid));
+}
+__device__ __forceinline__ bf16x8_t frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+    u32x4_t v = {a, b, c, d};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void stem_u8_fwd_mfma_kernel(StemArgs a) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // D[pixel][channel] = G[pixel][k] * Wsplit[k][channel]: a lane owns CHANNEL j of 16 pixels (accumulator v <-> pixel
+    // 8 * (v / 4) + 4 * h + v % 4 of the group), so one store instruction writes the 64 contiguous bytes of a pixel from 32 lanes.
+    // (With channels as rows a lane held 4-channel runs of one pixel: 8-byte stores in 16-byte runs at 64-byte stride, which stream at
+    // 3.3 TB/s where every other shape reaches 5.3 -- scripts/micro/store_patterns.hip.)
+    bf16x8_t W1, W2;                                  // k slots of channel j: see above
+    {
+        const float* wk = a.w + (size_t)j * 27;
+        unsigned hi[9], mid[9], lo[9], bh, bm, bl;
+        float b = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float w0 = wk[t * 3], w1 = wk[t * 3 + 1], w2 = wk[t * 3 + 2];
+            split3(w0 * a.ab[0] + w1 * a.ab[1] + w2 * a.ab[2], hi[t], mid[t], lo[t]);
+            b += w0 * a.ab[3] + w1 * a.ab[4] + w2 * a.ab[5];
+        }
+        split3(b, bh, bm, bl);
+        if (h == 0) {
+            W1 = frag(bfpair(hi[0], hi[1]), bfpair(hi[2], hi[3]), bfpair(hi[4], hi[5]), bfpair(hi[6], hi[7]));
+            W2 = frag(bfpair(mid[0], mid[1]), bfpair(mid[2], mid[3]), bfpair(mid[4], mid[5]), bfpair(mid[6], mid[7]));
+        } else {
+            W1 = frag(bfpair(hi[8], mid[8]), bfpair(lo[8], bh), bfpair(bm, bl), 0u);
+            W2 = frag(bfpair(lo[0], lo[1]), bfpair(lo[2], lo[3]), bfpair(lo[4], lo[5]), bfpair(lo[6], lo[7]));
+        }
+    }
+    float sc = 1.f, sh = 0.f;
+    if (AFFINE) { sc = a.scale[j]; sh = a.shift[j]; }
+    float s1 = 0.f, s2 = 0.f;
+    // byte offset of accumulator v's element inside a full group (pixels all inside the row)
+    unsigned voff[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) voff[v] = ((unsigned)(8 * (v >> 2) + 4 * h + (v & 3)) * (unsigned)a.ld + (unsigned)j) * 2u;
+    const unsigned row0 = blockIdx.x * (unsigned)RB, nitem = (unsigned)RB * a.gpr;
+    const unsigned ONE = 0x3f80u;
+    // The LAST group of a row starts at pixel Q - 32: it overlaps its neighbour instead of hanging over the row end, so every lane
+    // always has a real pixel, the stores need no clamping (the overlap is written twice with the same values) and only the
+    // statistics have to skip the `ovl` pixels that the neighbour already counted.  (Q >= 32; narrower outputs use the vector kernel.)
+    const unsigned ovl = a.gpr * 32 - (unsigned)a.Q;
+    // The nine bytes of the NEXT work unit are requested before this unit's stores are issued: memory operations retire in order,
+    // so a wait for loads issued behind the stores would also wait for the stores (measured: loads 40 us + stores 40 us + arithmetic
+    // 63 us added up to the kernel's 152 us).  The loop body has no memory operation under a branch for the same reason: at a join
+    // the compiler assumes the path that issued fewest and waits for everything.
+    // raw loads only (three unaligned 16-bit + three 8-bit loads): the bytes are taken apart at the top of the NEXT trip, behind a
+    // scheduling barrier -- left to itself the scheduler pulls those cheap ALU ops up between the stores, and their wait for the loads
+    // (issued after the previous trip's stores) then waits for those stores as well
+    auto fetch = [&](unsigned item, unsigned& row, unsigned& grp, unsigned short* r01, uint8_t* r2) {
+        const unsigned rr = fdiv(item, a.dG);      // wave-uniform
+        grp = item - rr * a.gpr;
+        row = row0 + rr;
+        const unsigned rowc = row < a.rows ? row : a.rows - 1;
+        const unsigned n = fdiv(rowc, a.dP), p = rowc - n * (unsigned)a.P;
+        const unsigned q = grp * 32 - (grp == a.gpr - 1 ? ovl : 0u) + j;
+        const uint8_t* s = a.g + ((size_t)n * a.H + 2 * p) * a.W + 2 * q;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            __builtin_memcpy(&r01[r], s + (size_t)r * a.W, 2);
+            r2[r] = s[(size_t)r * a.W + 2];
+        }
+    };
+    unsigned row, grp, row_n, grp_n;
+    unsigned short r01[3], r01_n[3];
+    uint8_t r2[3], r2_n[3];
+    fetch(wv, row_n, grp_n, r01_n, r2_n);
+    // (nothing pending at loop entry: otherwise the compiler's single wait at the loop head must cover this edge too -- vmcnt(0) -- and on
+    // the back edge that waits for the stores after all)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (unsigned item = wv; item < nitem; item += 4) {
+        row = row_n; grp = grp_n;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { r01[r] = r01_n[r]; r2[r] = r2_n[r]; }
+        if (row >= a.rows) break;
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned t[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            t[3 * r] = bfbits((float)(r01[r] & 0xffu));
+            t[3 * r + 1] = bfbits((float)(r01[r] >> 8));
+            t[3 * r + 2] = bfbits((float)r2[r]);
+        }
+        if (STEM_DBG(a, 1)) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t[i] = bfbits((float)((lane + i) & 255));
+        }
+        fetch(item + 4 < nitem ? item + 4 : item, row_n, grp_n, r01_n, r2_n);
+        const bf16x8_t G2 = frag(bfpair(t[0], t[1]), bfpair(t[2], t[3]), bfpair(t[4], t[5]), bfpair(t[6], t[7]));
+        const bf16x8_t G1 = h ? frag(bfpair(t[8], t[8]), bfpair(t[8], ONE), bfpair(ONE, ONE), 0u) : G2;
+        f32x16_t acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, W1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G2, W2, acc, 0, 0, 0);
+        const unsigned skip = grp == a.gpr - 1 ? ovl : 0u;        // pixels of this group that the previous group already covered
+        // group base (wave-uniform -> scalar registers): pixel row * Q + first pixel of the group, channel 0
+        const size_t gbase = ((size_t)row * a.Q + grp * 32 - skip) * a.ld * 2;
+        uint8_t* yb = (uint8_t*)a.y + (((size_t)__builtin_amdgcn_readfirstlane((unsigned)(gbase >> 32)) << 32) |
+                                       (size_t)__builtin_amdgcn_readfirstlane((unsigned)gbase));
+        unsigned short ob[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float x = acc[v];
+            if (AFFINE) {
+                x = fmaf(x, sc, sh);
+                if (a.relu) x = x > 0.f ? x : 0.f;
+            }
+            ob[v] = f2bf(x);
+        }
+        if (!AFFINE && !STEM_DBG(a, 4)) {
+            if (skip == 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float x = bf2f(ob[v]);
+                    s1 += x;
+                    s2 = fmaf(x, x, s2);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float x = (unsigned)(8 * (v >> 2) + 4 * h + (v & 3)) >= skip ? bf2f(ob[v]) : 0.f;
+                    s1 += x;
+                    s2 = fmaf(x, x, s2);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            if (!STEM_DBG(a, 2) || ob[v] == 0x1234) *reinterpret_cast<bf16_t*>(yb + voff[v]) = ob[v];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (AFFINE || !a.part) return;
+    __shared__ float red[4][2][K1];
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (h == 0) { red[wv][0][j] = s1; red[wv][1][j] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2 * K1) {
+        const int st = threadIdx.x >> 5, ch = threadIdx.x & 31;
+        a.part[((size_t)blockIdx.x * 2 + st) * K1 + ch] = (red[0][st][ch] + red[1][st][ch]) + (red[2][st][ch] + red[3][st][ch]);
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_u8_wgrad_mfma_kernel(StemArgs a) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kg = lane >> 4;         // A: row = channel c (c + 16 in the second product); B: column = tap c; k = 8 pixels from 8 * kg
+    const int tr = c < 9 ? c / 3 : 0, tc = c < 9 ? c % 3 : 0;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const unsigned row0 = blockIdx.x * (unsigned)RB, nitem = (unsigned)RB * a.gpr;
+    const bf16_t* dy = (const bf16_t*)a.dy;
+    for (unsigned item = wv; item < nitem; item += 4) {
+        const unsigned rr = fdiv(item, a.dG), grp = item - rr * a.gpr, row = row0 + rr;      // wave-uniform
+        if (row >= a.rows) break;
+        const unsigned n = fdiv(row, a.dP), p = row - n * (unsigned)a.P;
+        const unsigned q0 = grp * 32 + 8 * kg;
+        const bf16_t* dp = dy + (size_t)row * a.Q * a.ld + c;
+        const uint8_t* s = a.g + ((size_t)n * a.H + 2 * p + tr) * a.W + tc;
+        unsigned d0[8], d1[8], gb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned q = q0 + e;
+            const bool ok = q < (unsigned)a.Q;
+            const unsigned qc = ok ? q : (unsigned)a.Q - 1;
+            const unsigned v0 = dp[(size_t)qc * a.ld], v1 = dp[(size_t)qc * a.ld + 16];
+            d0[e] = ok ? v0 : 0u;                     // (pixels beyond the row end contribute nothing)
+            d1[e] = ok ? v1 : 0u;
+            gb[e] = s[2 * qc];
+        }
+        unsigned g16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g16[e] = c < 9 ? bfbits((float)gb[e]) : (c == 9 ? 0x3f80u : 0u);
+        const bf16x8_t A0 = frag(bfpair(d0[0], d0[1]), bfpair(d0[2], d0[3]), bfpair(d0[4], d0[5]), bfpair(d0[6], d0[7]));
+        const bf16x8_t A1 = frag(bfpair(d1[0], d1[1]), bfpair(d1[2], d1[3]), bfpair(d1[4], d1[5]), bfpair(d1[6], d1[7]));
+        const bf16x8_t B = frag(bfpair(g16[0], g16[1]), bfpair(g16[2], g16[3]), bfpair(g16[4], g16[5]), bfpair(g16[6], g16[7]));
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B, acc1, 0, 0, 0);
+    }
+    // lane (tap c, kg): acc0[v] = channel 4 * kg + v, acc1[v] = channel 16 + 4 * kg + v
+    __shared__ float red[4][K1][16];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        red[wv][4 * kg + v][c] = acc0[v];
+        red[wv][16 + 4 * kg + v][c] = acc1[v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K1 * 10; i += 256) {
+        const int k = i / 10, t = i - k * 10;
+        a.part[(size_t)blockIdx.x * (K1 * 10) + i] = (red[0][k][t] + red[1][k][t]) + (red[2][k][t] + red[3][k][t]);
+    }
+}
+
 // one block per output channel k: 64 row groups x 10 sums over the block partials (fp64, fixed order), then the 27 master-gradient
 // entries of that channel
 __global__ __launch_bounds__(640) void stem_u8_wgrad_reduce_kernel(const float* part, int nblk, const float* ab, float* dw, int accumulate) {
@@ -247,13 +475,25 @@ StemArgs stem_args(const ifcbk_conv_desc* d, const uint8_t* g, const float* w, c
     a.M = (unsigned)((int64_t)d->N * d->P * d->Q);
     a.dPQ = make_fastdiv(a.PQ);
     a.dQ = make_fastdiv((unsigned)d->Q);
+    a.rows = (unsigned)(d->N * d->P);
+    a.gpr = (unsigned)cdiv(d->Q, 32);
+    a.dP = make_fastdiv((unsigned)d->P);
+    a.dG = make_fastdiv(a.gpr);
+#ifdef IFCBK_EXPERIMENT_STEM
+    a.dbg = getenv("IFCBK_STEM_DBG") ? atoi(getenv("IFCBK_STEM_DBG")) : 0;
+#endif
     return a;
 }
 
 }  // namespace
 
 // rows of the BatchNorm partial sums ifcbk_stem_u8_fwd writes (= its grid); 0: this descriptor is not served
-extern "C" int ifcbk_stem_u8_rows(const ifcbk_conv_desc* d) { return stem_ok(d) ? cdiv((int64_t)d->N * d->P * d->Q, PIXB) : 0; }
+// (bf16: the MFMA kernels, one block per RB output rows; fp32 parity mode: the vector-FMA kernels, one block per PIXB pixels)
+static bool stem_mfma(const ifcbk_conv_desc* d) { return d->dtype == IFCBK_BF16 && d->Q >= 32; }
+extern "C" int ifcbk_stem_u8_rows(const ifcbk_conv_desc* d) {
+    if (!stem_ok(d)) return 0;
+    return stem_mfma(d) ? cdiv((int64_t)d->N * d->P, RB) : cdiv((int64_t)d->N * d->P * d->Q, PIXB);
+}
 
 extern "C" size_t ifcbk_stem_u8_wgrad_workspace(const ifcbk_conv_desc* d) {
     return stem_ok(d) ? (size_t)ifcbk_stem_u8_rows(d) * K1 * 10 * sizeof(float) : 0;
@@ -270,9 +510,11 @@ extern "C" int ifcbk_stem_u8_fwd(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const
     const bool f32 = d->dtype == IFCBK_F32;
     if (scale) {
         if (f32) hipLaunchKernelGGL((stem_u8_fwd_kernel<float, true>), grid, blk, 0, st, a);
+        else if (stem_mfma(d)) hipLaunchKernelGGL((stem_u8_fwd_mfma_kernel<true>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((stem_u8_fwd_kernel<bf16_t, true>), grid, blk, 0, st, a);
     } else {
         if (f32) hipLaunchKernelGGL((stem_u8_fwd_kernel<float, false>), grid, blk, 0, st, a);
+        else if (stem_mfma(d)) hipLaunchKernelGGL((stem_u8_fwd_mfma_kernel<false>), grid, blk, 0, st, a);
         else hipLaunchKernelGGL((stem_u8_fwd_kernel<bf16_t, false>), grid, blk, 0, st, a);
     }
     IFCBK_LAUNCH_CHECK(ctx, "stem_u8_fwd");
@@ -290,6 +532,7 @@ extern "C" int ifcbk_stem_u8_wgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, con
     const int nblk = ifcbk_stem_u8_rows(d);
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == IFCBK_F32) hipLaunchKernelGGL(stem_u8_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, a);
+    else if (stem_mfma(d)) hipLaunchKernelGGL(stem_u8_wgrad_mfma_kernel, dim3(nblk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(stem_u8_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, a);
     IFCBK_LAUNCH_CHECK(ctx, "stem_u8_wgrad");
     hipLaunchKernelGGL(stem_u8_wgrad_reduce_kernel, dim3(K1), dim3(640), 0, st, (const float*)ctx->ws, nblk, ab, dw, accumulate);
