@@ -167,15 +167,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, int ldx, cons
     }
     __syncthreads();
     const int64_t total = M * cpr;
-    int64_t i = (int64_t)blockIdx.x * (256 * EW_ITER) + threadIdx.x;
-#pragma unroll 2
-    for (int it = 0; it < EW_ITER; ++it, i += 256) {
-        if (i >= total) break;
-        uint32_t m = fdiv((uint32_t)i, fcpr);
-        int c = ((int)i - (int)m * cpr) * E;
+    const int64_t i0 = (int64_t)blockIdx.x * (256 * EW_ITER) + threadIdx.x;
+    // All EW_ITER loads of a thread are issued before its first store: memory operations retire in order, so a load issued behind a
+    // store cannot be waited for without waiting for that store's round trip too (load -> store -> load -> store was four serial round
+    // trips per thread; trips past the end re-read the last chunk and store nothing)
+    typename Chunk<T>::raw_t rx[EW_ITER], rq[EW_ITER];
+    uint32_t mm[EW_ITER];
+    int cc[EW_ITER];
+#pragma unroll
+    for (int it = 0; it < EW_ITER; ++it) {
+        const int64_t i = i0 + it * 256 < total ? i0 + it * 256 : total - 1;
+        mm[it] = fdiv((uint32_t)i, fcpr);
+        cc[it] = ((int)i - (int)mm[it] * cpr) * E;
+        rx[it] = Chunk<T>::load_raw(x + (int64_t)mm[it] * ldx + cc[it]);
+        if (RES) rq[it] = Chunk<T>::load_raw(res + (int64_t)mm[it] * ldr + cc[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < EW_ITER; ++it) {
+        if (i0 + it * 256 >= total) break;
+        const int c = cc[it];
         float f[E], r[E];
-        Chunk<T>::load(x + (int64_t)m * ldx + c, f);
-        if (RES) Chunk<T>::load(res + (int64_t)m * ldr + c, r);
+        Chunk<T>::widen(rx[it], f);
+        if (RES) Chunk<T>::widen(rq[it], r);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             float o = f[j] * coef[c + j] + coef[C + c + j];
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, int ldx, cons
             if (RELU) o = fmaxf(o, 0.f);
             f[j] = o;
         }
-        Chunk<T>::store(y + (int64_t)m * ldy + c, f);
+        Chunk<T>::store(y + (int64_t)mm[it] * ldy + c, f);
     }
 }
 
