@@ -109,7 +109,7 @@ def test_family_fp32_parity_with_the_reference_arithmetic(name, nc, B, bn):
     print(name, 'fp32 parameter gradients: worst tensor', worst, '%.2e' % errs[worst], '| zero-gradient biases:', len(dead))
     # (without BatchNorm the gradients agree to ~2e-6 -- alexnet -- unless a max pool's two largest window elements differ by less
     # than the 1e-6 forward distance: the arg-max then flips and one gradient element takes the other route.  vgg11 at batch 2
-    # has 2 such elements among 800 k behind features.15 (scripts/dbg_vgg_acts.py), worth 2e-3 of the gradient norm)
+    # has 2 such elements among 800 k behind features.15 (scripts/diag_vgg_acts.py), worth 2e-3 of the gradient norm)
     med = sorted(errs.values())[len(errs) // 2]
     print(name, 'median tensor %.2e' % med)
     # (densenet121: 121 random-init BatchNorm layers behind a max pool; the first BatchNorm's gradient collects all of it)
@@ -186,7 +186,7 @@ def test_family_node_local_parity(name, nc, B, bn, dtype):
         # densenet's norm0.weight: the gradient that reaches the first BatchNorm through 120 layers is nearly uncorrelated with
         # the normalised activation, sum(dz * xhat) over 37,632 pixels cancels to ~1e-5 of its terms and the fp32 summation ORDER
         # (tile partials here, a running sum in autograd) shows: 4e-2 on that one tensor, with or without the pool fusion, while
-        # dbeta / dW / the activation gradient of the same node agree to 1e-5 (scripts/dbg_family_nodes.py)
+        # dbeta / dW / the activation gradient of the same node agree to 1e-5 (scripts/diag_family_nodes.py)
         dg = worst.pop('dgamma')
         assert dg < (0.1 if name.startswith('densenet') else 5e-5)
         assert max(worst.values()) < 5e-5
