@@ -387,50 +387,32 @@ __global__ __launch_bounds__(256) void stem_u8_wgrad_mfma_kernel(StemArgs a) {
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const unsigned row0 = blockIdx.x * (unsigned)RB, nitem = (unsigned)RB * a.gpr;
     const bf16_t* dy = (const bf16_t*)a.dy;
-    // the 24 loads of the next unit are in flight while this unit is packed and multiplied (raw values only; see the forward kernel)
-    auto fetch = [&](unsigned item, unsigned& row, unsigned& grp, unsigned short* r0, unsigned short* r1, uint8_t* rg) {
-        const unsigned rr = fdiv(item, a.dG);      // wave-uniform
-        grp = item - rr * a.gpr;
-        row = row0 + rr;
-        const unsigned rowc = row < a.rows ? row : a.rows - 1;
-        const unsigned n = fdiv(rowc, a.dP), p = rowc - n * (unsigned)a.P;
-        const unsigned q0 = grp * 32 + 8 * kg;
-        const bf16_t* dp = dy + (size_t)rowc * a.Q * a.ld + c;
-        const uint8_t* s = a.g + ((size_t)n * a.H + 2 * p + tr) * a.W + tc;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned q = q0 + e, qc = q < (unsigned)a.Q ? q : (unsigned)a.Q - 1;
-            r0[e] = dp[(size_t)qc * a.ld];
-            r1[e] = dp[(size_t)qc * a.ld + 16];
-            rg[e] = s[2 * qc];
-        }
-    };
-    unsigned row, grp, row_n, grp_n;
-    unsigned short r0[8], r1[8], r0_n[8], r1_n[8];
-    uint8_t rg[8], rg_n[8];
-    fetch(wv, row_n, grp_n, r0_n, r1_n, rg_n);
     for (unsigned item = wv; item < nitem; item += 4) {
-        row = row_n; grp = grp_n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { r0[e] = r0_n[e]; r1[e] = r1_n[e]; rg[e] = rg_n[e]; }
+        const unsigned rr = fdiv(item, a.dG), grp = item - rr * a.gpr, row = row0 + rr;      // wave-uniform
         if (row >= a.rows) break;
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(item + 4 < nitem ? item + 4 : item, row_n, grp_n, r0_n, r1_n, rg_n);
+        const unsigned n = fdiv(row, a.dP), p = row - n * (unsigned)a.P;
         const unsigned q0 = grp * 32 + 8 * kg;
-        unsigned d0[8], d1[8], g16[8];
+        const bf16_t* dp = dy + (size_t)row * a.Q * a.ld + c;
+        const uint8_t* s = a.g + ((size_t)n * a.H + 2 * p + tr) * a.W + tc;
+        unsigned d0[8], d1[8], gb[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const bool ok = q0 + e < (unsigned)a.Q;       // (pixels beyond the row end contribute nothing)
-            d0[e] = ok ? (unsigned)r0[e] : 0u;
-            d1[e] = ok ? (unsigned)r1[e] : 0u;
-            g16[e] = c < 9 ? bfbits((float)rg[e]) : (c == 9 ? 0x3f80u : 0u);
+            const unsigned q = q0 + e;
+            const bool ok = q < (unsigned)a.Q;
+            const unsigned qc = ok ? q : (unsigned)a.Q - 1;
+            const unsigned v0 = dp[(size_t)qc * a.ld], v1 = dp[(size_t)qc * a.ld + 16];
+            d0[e] = ok ? v0 : 0u;                     // (pixels beyond the row end contribute nothing)
+            d1[e] = ok ? v1 : 0u;
+            gb[e] = s[2 * qc];
         }
+        unsigned g16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g16[e] = c < 9 ? bfbits((float)gb[e]) : (c == 9 ? 0x3f80u : 0u);
         const bf16x8_t A0 = frag(bfpair(d0[0], d0[1]), bfpair(d0[2], d0[3]), bfpair(d0[4], d0[5]), bfpair(d0[6], d0[7]));
         const bf16x8_t A1 = frag(bfpair(d1[0], d1[1]), bfpair(d1[2], d1[3]), bfpair(d1[4], d1[5]), bfpair(d1[6], d1[7]));
         const bf16x8_t B = frag(bfpair(g16[0], g16[1]), bfpair(g16[2], g16[3]), bfpair(g16[4], g16[5]), bfpair(g16[6], g16[7]));
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, B, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     }
     // lane (tap c, kg): acc0[v] = channel 4 * kg + v, acc1[v] = channel 16 + 4 * kg + v
     __shared__ float red[4][K1][16];
