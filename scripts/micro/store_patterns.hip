@@ -33,6 +33,12 @@ __global__ __launch_bounds__(256) void k(uint8_t* y, unsigned nitems_total, unsi
         } else if (P == 5) {     // 8 B per lane, 8 lanes = one pixel's 64 B, 512 B contiguous per instruction
 #pragma unroll
             for (int r = 0; r < 4; ++r) *reinterpret_cast<uint2*>(base + r * 512 + lane * 8) = make_uint2(v, v + r);
+        } else if (P == 6) {     // 16x16 MFMA output, rows = pixels (lane & 15), 4 channels per lane: 8 B/lane, 32-byte runs at 128 B stride
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<uint2*>(base + (lane & 15) * 128 + r * 32 + (lane >> 4) * 8) = make_uint2(v, v + r);
+        } else if (P == 7) {     // the same after exchanging halves between lane pairs: 16 B/lane, 64-byte runs at 128 B stride
+#pragma unroll
+            for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4*>(base + (lane & 15) * 128 + r * 64 + (lane >> 4) * 16) = make_uint4(v, v + 1, v + 2, v + r);
         }
     }
 }
@@ -46,9 +52,10 @@ int main() {
     hipEventCreate(&e0); hipEventCreate(&e1);
     const unsigned grid = (nitems + 39) / 40;
     const char* names[] = {"16 B/lane, 1 KB contiguous", "8 B/lane, 16 B runs at 64 B stride", "16 B/lane, 32 B runs at 64 B stride",
-                           "2 B/lane, 64 B rows", "4 B/lane, 64 B rows", "8 B/lane, 512 B contiguous"};
+                           "2 B/lane, 64 B rows", "4 B/lane, 64 B rows", "8 B/lane, 512 B contiguous",
+                           "8 B/lane, 32 B runs at 128 B stride", "16 B/lane, 64 B runs at 128 B stride"};
     for (int rep = 0; rep < 2; ++rep)
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < 8; ++p) {
         float best = 1e9f;
         for (int r = 0; r < 5; ++r) {
             hipEventRecord(e0);
@@ -59,6 +66,8 @@ int main() {
                 case 3: k<3><<<grid, 256>>>(y, nitems, r); break;
                 case 4: k<4><<<grid, 256>>>(y, nitems, r); break;
                 case 5: k<5><<<grid, 256>>>(y, nitems, r); break;
+                case 6: k<6><<<grid, 256>>>(y, nitems, r); break;
+                case 7: k<7><<<grid, 256>>>(y, nitems, r); break;
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);
