@@ -198,6 +198,7 @@ def run_mode_leg(args, local):
     ips, ms, n = run(int(best), args.infer_rois)
     tf = ips * 11.423e-3
     cpu_eval = None
+    hipgraph, lanes_eval = bool(eng.graph_eval), eng.NL_eval
     if not args.no_cpu_baseline:
         del eng
         torch.cuda.empty_cache()
@@ -206,7 +207,7 @@ def run_mode_leg(args, local):
                          'in HBM), batch %s, hipGraph-replayed eval forward, preprocess + softmax included, file writes excluded '
                          '(BASELINE.json configs[3])' % (args.classes, n, POOL, best),
                 images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), batch=int(best), rois=n, seconds=round(n / ips, 2),
-                batch_sweep_100k=sweep, hipgraph=bool(eng.graph_eval), program_lanes=eng.NL_eval,
+                batch_sweep_100k=sweep, hipgraph=hipgraph, program_lanes=lanes_eval,
                 roofline=dict(bound='mfma', achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
                               frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4), flops_per_image=11.423e9,
                               note='whole RUN step (preprocess + 94 convs with folded BatchNorm + pools + head + softmax) against the '

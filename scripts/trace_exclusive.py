@@ -64,3 +64,18 @@ for n in tot:
 print('%-46s %9s %9s %9s' % ('kernel', 'excl ms', 'shared ms', 'sum ms'))
 for k, (a, b, c) in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:40]:
     print('%-46s %9.3f %9.3f %9.3f' % (k, a / nsteps / 1e6, b / nsteps / 1e6, c / nsteps / 1e6))
+# idle gaps: which kernel ended last before the gap, which one started after it
+gaps = defaultdict(lambda: [0, 0.0])
+active2, last_end, prev2 = 0, None, t0
+for t, d, n in ev:
+    if active2 == 0 and d == 1 and last_end is not None and t > prev2:
+        g = gaps[(short(last_end), short(n))]
+        g[0] += 1
+        g[1] += t - prev2
+    active2 += d
+    if d == -1:
+        last_end = n
+    prev2 = t
+print('\nidle gaps by (kernel that ended, kernel that started): count per step, ms per step')
+for (a, b), (cnt, ns) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+    print('%-40s -> %-40s %6.1f %8.3f' % (a[:40], b[:40], cnt / nsteps, ns / nsteps / 1e6))
