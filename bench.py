@@ -441,6 +441,7 @@ def main():
             ev_dom = {}
             for sl in (0, 1):                                 # one event-flagged op table per input slot
                 eng._select_slot(sl)
+                eng.in_kind[sl] = eng.in_kind[cur]            # (both slots will hold ROIs of the same kind: the plan is per kind)
                 ev_dom[sl] = eng.plan(B).step.timed(domops)
             eng._select_slot(cur)
     torch.cuda.synchronize()
