@@ -16,14 +16,14 @@ BF16, F32 = 0, 1
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
  OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD, OP_CONV_DGRAD_BNSTAT_TAB,
- OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD) = range(1, 37)
+ OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD, OP_CONV_FWD_AFFINE_MAXPOOL) = range(1, 38)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
             24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd', 31: 'conv_dgrad',
-            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad'}
+            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine'}
 
 
 class ConvDesc(C.Structure):
@@ -81,6 +81,8 @@ _PROTOS = {
     'ifcbk_last_error': (C.c_char_p, [_vp]),
     'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'ifcbk_conv2d_fwd_affine_maxpool_ok': (_i, [C.POINTER(ConvDesc)]),
+    'ifcbk_conv2d_fwd_affine_maxpool': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_dgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_wgrad': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
     'ifcbk_conv2d_wgrad_segments': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp]),

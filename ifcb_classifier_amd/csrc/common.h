@@ -150,6 +150,9 @@ int ifcbk_conv_rows_blocks(int N, int Pout);
 int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int W, int ldx, int P, int Q, int ldy, int pad_h,
                            int pad_w, const void* x, const void* w, void* y, float* part, const float* scale,
                            const float* shift, int relu, hipStream_t st);
+bool ifcbk_conv_rows_pool_ok(int dtype, int cin, int cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int P, int Q);
+int ifcbk_conv_rows_pool_launch(ifcbk_ctx* ctx, int N, int H, int W, int ldx, int P, int Q, int pad_h, int pad_w, const void* x,
+                                const void* w, void* y, int ldy, const float* scale, const float* shift, int relu, hipStream_t st);
 int ifcbk_num_cus();
 // conv_big.hip: wide-tile (256/320 pixels x 128..256 channels) ping-pong kernel; plan = does it serve this GEMM, and with which tile
 bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt, int* tn);

@@ -686,6 +686,36 @@ extern "C" int ifcbk_conv2d_fwd_affine(ifcbk_ctx* ctx, const ifcbk_conv_desc* d,
     return conv_fwd_impl(ctx, d, x, w, y, nullptr, scale, shift, residual, ldr, relu, stream);
 }
 
+// eval: conv + folded BatchNorm affine (+ReLU) + the 3x3 / stride-2 / unpadded max pool that is the activation's only consumer, in one
+// pass (the row-streaming kernel keeps the pooled maxima in registers): 1 where the descriptor is served
+extern "C" int ifcbk_conv2d_fwd_affine_maxpool_ok(const ifcbk_conv_desc* d) {
+    return d && ifcbk_conv_rows_pool_ok(d->dtype, d->C, d->K, d->R, d->S, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->P, d->Q) ? 1 : 0;
+}
+
+extern "C" int ifcbk_conv2d_fwd_affine_maxpool(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y_pooled,
+                                               int ldp, const float* scale, const float* shift, int relu, void* stream) {
+    if (!ifcbk_conv2d_fwd_affine_maxpool_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_fwd_affine_maxpool: not served by the row-streaming kernel");
+    if (!x || !w || !y_pooled || !scale || !shift || ldp < d->K || ldp % 8) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine_maxpool: bad operand");
+    {
+        // (the un-pooled activation is never stored: only its shape must be consistent, not its size inside the descriptor window)
+        ifcbk_conv_desc one = *d;
+        one.N = 1;
+        if (int e = check_desc(ctx, &one)) return e;
+    }
+    // image groups inside the 2 GiB descriptor window of the input
+    const int64_t per = (int64_t)d->H * d->W * d->ldx * 2;
+    const int64_t G = per > 0 ? ((1ll << 31) - 1) / per : d->N;
+    if (G < 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_affine_maxpool: one image exceeds the descriptor window");
+    const int Pp = (d->P - 3) / 2 + 1, Qp = (d->Q - 3) / 2 + 1;
+    for (int64_t g0 = 0; g0 < d->N; g0 += G) {
+        const int n = (int)(d->N - g0 < G ? d->N - g0 : G);
+        const int e = ifcbk_conv_rows_pool_launch(ctx, n, d->H, d->W, d->ldx, d->P, d->Q, d->pad_h, d->pad_w, (const char*)x + g0 * per, w,
+                                                  (char*)y_pooled + g0 * Pp * Qp * ldp * 2, ldp, scale, shift, relu, (hipStream_t)stream);
+        if (e) return e;
+    }
+    return 0;
+}
+
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
                          const FwdSegs* seg) {

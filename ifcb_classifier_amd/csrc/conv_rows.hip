@@ -24,6 +24,7 @@ struct RowsArgs {
     unsigned xbytes;
     int N, H, W, ldx, P, Q, ldy, ph, pw;
     int rseg, nseg, mtiles;
+    int Pp, Qp;             // POOL: the pooled output [N,Pp,Qp,ldy] is what is written
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -31,8 +32,13 @@ constexpr int RSEG = 16;        // output rows per block
 constexpr int MT_MAX = 10;      // 16-pixel tiles per output row (Q <= 160)
 constexpr int NPX = 16 * MT_MAX + 4;   // pixels of an LDS row image: input columns -2 .. 16*MT_MAX+1
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_rows3x3(RowsArgs a) {
+// POOL (eval only): the conv's folded-BatchNorm + ReLU output feeds ONLY a 3x3 / stride-2 / unpadded max pool (Conv2d_2b -> maxpool1):
+// the activated row never leaves the block -- each thread keeps the running column-pooled maximum of its (pooled pixel, channel chunk)
+// items in registers over the three conv rows of a pooled row and writes the pooled row; a block owns 8 pooled rows = 17 conv rows (the
+// last one is the next block's first: recomputed).  Bit-identical to the affine epilogue followed by ifcbk_maxpool_fwd (rounding to the
+// storage type is monotone), without the 708 MB activation write and read per batch of 256.
+template <int CIN, int COUT, bool POOL = false>
+__global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel
     constexpr int NTL = COUT / 16;                   // output-channel tiles
     constexpr int KG = CIN / 32;                     // MFMA k groups per tap
@@ -53,7 +59,9 @@ __global__ __launch_bounds__(256) void conv_rows3x3(RowsArgs a) {
     const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int n = bid / a.nseg;
     const int p0 = (bid - n * a.nseg) * a.rseg;
-    const int p1 = min(p0 + a.rseg, a.P);
+    const int p1 = min(p0 + a.rseg + (POOL ? 1 : 0), a.P);
+    constexpr int NI = POOL ? (((16 * MT_MAX - 3) / 2 + 1) * (COUT / 8) + 255) / 256 : 1;      // pooled items of a thread
+    uint4 run[NI];                // running maxima of a thread's pooled items, packed bf16 (the values are bf16 already): 4 registers each
 
     // ---- filter fragments (MFMA A operand): lane (row l&15, k group l>>4) of tile nt holds 8 input channels of a tap
     const int frow = lane & 15, fkg = lane >> 4;
@@ -147,7 +155,45 @@ __global__ __launch_bounds__(256) void conv_rows3x3(RowsArgs a) {
         __syncthreads();
         if (NSLOT == 3 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // the slot of row p-ph is free: every wave is past its multiply
         // ---- output row: 16-byte chunks, thread t always owns channel chunk t % CPO
-        {
+        if (POOL) {
+            const int cc = t % CPO, nn = cc * 8;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = a.ep_scale[nn + j]; sh[j] = a.ep_shift[nn + j]; }
+            const int rel = p - p0;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int qq = (t + 256 * k) / CPO;
+                if (qq >= a.Qp) break;
+                float h[8];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    float fv[8];
+                    Chunk<bf16_t>::load(sC + (2 * qq + s) * LDC + nn, fv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = fv[j] * sc[j] + sh[j];
+                        if (a.ep_relu) v = fmaxf(v, 0.f);
+                        v = Chunk<bf16_t>::round(v);
+                        h[j] = s ? fmaxf(h[j], v) : v;
+                    }
+                }
+                if (rel) {
+                    float rv[8];
+                    unpack8(run[k], rv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rv[j] = fmaxf(rv[j], h[j]);
+                    if (rel & 1) {
+                        run[k] = pack8(rv);
+                    } else {
+                        Chunk<bf16_t>::store((bf16_t*)a.y + ((size_t)(n * a.Pp + (p >> 1) - 1) * a.Qp + qq) * a.ldy + nn, rv);
+                        run[k] = pack8(h);
+                    }
+                } else {
+                    run[k] = pack8(h);
+                }
+            }
+        } else {
             const int cc = t % CPO;
             const int nn = cc * 8;
             float sc[8], sh[8];
@@ -226,10 +272,29 @@ int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int 
     a.xbytes = (unsigned)((int64_t)N * H * W * ldx * 2);
     a.N = N; a.H = H; a.W = W; a.ldx = ldx; a.P = P; a.Q = Q; a.ldy = ldy; a.ph = pad_h; a.pw = pad_w;
     a.rseg = RSEG; a.nseg = (P + RSEG - 1) / RSEG; a.mtiles = (Q + 15) / 16;
+    a.Pp = a.Qp = 0;
     const dim3 grid(N * a.nseg), block(256);
     if (cin == 32 && cout == 32) hipLaunchKernelGGL((conv_rows3x3<32, 32>), grid, block, 0, st, a);
     else if (cin == 32 && cout == 64) hipLaunchKernelGGL((conv_rows3x3<32, 64>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_rows3x3<64, 32>), grid, block, 0, st, a);
     IFCBK_LAUNCH_CHECK(ctx, "conv_rows3x3");
+    return 0;
+}
+
+// eval: conv (3x3 / stride 1) + folded BatchNorm affine (+ReLU) + max pool 3x3 / stride 2 / no padding in one pass (32 -> 64 channels)
+bool ifcbk_conv_rows_pool_ok(int dtype, int cin, int cout, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w, int P, int Q) {
+    return ifcbk_conv_rows_ok(dtype, cin, cout, R, S, stride_h, stride_w, pad_h, pad_w, Q) && cin == 32 && cout == 64 && P >= 3 && Q >= 3;
+}
+
+int ifcbk_conv_rows_pool_launch(ifcbk_ctx* ctx, int N, int H, int W, int ldx, int P, int Q, int pad_h, int pad_w, const void* x,
+                                const void* w, void* y, int ldy, const float* scale, const float* shift, int relu, hipStream_t st) {
+    RowsArgs a;
+    a.x = x; a.w = w; a.y = y; a.part = nullptr; a.ep_scale = scale; a.ep_shift = shift; a.ep_relu = relu;
+    a.xbytes = (unsigned)((int64_t)N * H * W * ldx * 2);
+    a.N = N; a.H = H; a.W = W; a.ldx = ldx; a.P = P; a.Q = Q; a.ldy = ldy; a.ph = pad_h; a.pw = pad_w;
+    a.Pp = (P - 3) / 2 + 1; a.Qp = (Q - 3) / 2 + 1;
+    a.rseg = RSEG; a.nseg = (a.Pp + RSEG / 2 - 1) / (RSEG / 2); a.mtiles = (Q + 15) / 16;
+    hipLaunchKernelGGL((conv_rows3x3<32, 64, true>), dim3(N * a.nseg), dim3(256), 0, st, a);
+    IFCBK_LAUNCH_CHECK(ctx, "conv_rows3x3(pool)");
     return 0;
 }

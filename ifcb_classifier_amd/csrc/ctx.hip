@@ -121,6 +121,9 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                            (int)o->i[0], (o->flags >> 2) & 1, st);
         case IFCBK_OP_CONV_DGRAD: return ifcbk_conv2d_dgrad(c, &o->u.conv, p[0], p[1], p[2], acc, st);
         case IFCBK_OP_CONV_WGRAD: return ifcbk_conv2d_wgrad(c, &o->u.conv, p[0], p[1], (float*)p[2], acc, st);
+        case IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL:
+            return ifcbk_conv2d_fwd_affine_maxpool(c, &o->u.conv, p[0], p[1], p[2], (int)o->i[0], (const float*)p[3], (const float*)p[4],
+                                                   (o->flags >> 2) & 1, st);
         case IFCBK_OP_STEM_U8_FWD:
             return ifcbk_stem_u8_fwd(c, &o->u.conv, (const uint8_t*)p[0], (const float*)p[1], (const float*)p[2], p[3], (float*)p[4],
                                      (const float*)p[5], (const float*)p[6], (o->flags >> 2) & 1, st);
@@ -499,6 +502,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
             break;
         }
+        case IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL: snprintf(name, cap, "conv_rows3x3<%d, %d, true>", o->u.conv.C, o->u.conv.K); break;
         case IFCBK_OP_STEM_U8_FWD: snprintf(name, cap, "stem_u8_fwd_kernel"); break;
         case IFCBK_OP_STEM_U8_WGRAD: snprintf(name, cap, "stem_u8_wgrad_kernel"); break;
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
@@ -535,6 +539,12 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
                    wb = (double)d.K * d.R * d.S * d.C * 2;
             by = xin + yout + wb + ((o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? xin : 0);      // + one read of the producer's raw output
+            break;
+        }
+        case IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL: {
+            const ifcbk_conv_desc& d = o->u.conv;
+            fl = 2.0 * d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
+            by = (double)d.N * d.H * d.W * d.C * 2 + (double)d.N * ((d.P - 3) / 2 + 1) * ((d.Q - 3) / 2 + 1) * d.K * 2;
             break;
         }
         case IFCBK_OP_STEM_U8_FWD: case IFCBK_OP_STEM_U8_WGRAD: {

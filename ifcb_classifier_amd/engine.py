@@ -711,6 +711,15 @@ class Engine:
                         fused_pool[prod[0]] = (m, kk)
         fused_pool_nodes = {v[0] for v in fused_pool.values()}
         self.fused_pool = fused_pool
+        # eval twin: conv + folded BatchNorm + ReLU + that max pool in ONE kernel where the row-streaming conv serves the layer
+        # (inception Conv2d_2b -> maxpool1): the 708 MB activation of a batch of 256 is neither written nor read back
+        fused_pool_eval = {}
+        if os.environ.get('IFCBK_FUSE_POOL_EVAL', '1') != '0' and not self.plan_only:
+            for cn, (pn, pk) in fused_pool.items():
+                if (pn.ph == 0 and pn.pw == 0 and cn.y.buf.C == cn.K
+                        and self.ctx.lib.ifcbk_conv2d_fwd_affine_maxpool_ok(C.byref(self._conv_desc(cn, N)))):
+                    fused_pool_eval[cn] = pn
+        fused_pool_eval_nodes = set(fused_pool_eval.values())
         # conv c whose input is the private BN+ReLU activation of conv n: c's input-gradient kernel also reduces n's BN
         # backward sums in its epilogue (ifcbk_conv2d_dgrad_bnstat) and n's BN backward skips its reduction pass
         bnstat_of = {}        # consumer conv -> producer conv
@@ -894,6 +903,12 @@ class Engine:
                                 p=(gu8, self._pptr(ckey), gab, self._aptr(n.y), None, self._stat(n, 4), self._stat(n, 5)),
                                 flags=4 if n.relu else 0, conv=d, lane=Le, reads=[ra(n.x)], writes=[ra(n.y)])
                         continue
+                    if not train and n in fused_pool_eval:
+                        pn = fused_pool_eval[n]
+                        lst.add(_lib.OP_CONV_FWD_AFFINE_MAXPOOL, n.name + '+' + pn.name,
+                                p=(self._aptr(n.x), wk, self._aptr(pn.y), self._stat(n, 4), self._stat(n, 5)),
+                                i=(pn.y.buf.C,), flags=4 if n.relu else 0, conv=d, lane=Le, reads=[ra(n.x)], writes=[ra(pn.y)])
+                        continue
                     if not train:
                         # inference: eval-BN affine (+residual) + ReLU fused into the conv epilogue; no raw tensor
                         lst.add(_lib.OP_CONV_FWD_AFFINE, n.name,
@@ -992,6 +1007,8 @@ class Engine:
                     if n.kind == 'max':
                         if train and n in fused_pool_nodes:
                             continue              # done by the producing conv's bn_apply_maxpool
+                        if not train and n in fused_pool_eval_nodes:
+                            continue              # done in the producing conv's epilogue
                         lst.add(_lib.OP_MAXPOOL_FWD, n.name, p=(self._aptr(n.x), self._aptr(n.y), _vp(self.argmax[k]) if train else None), pool=pd,
                                 lane=Lx, reads=[ra(n.x)], writes=[ra(n.y), ram(k)])
                     else:

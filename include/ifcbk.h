@@ -72,6 +72,14 @@ int ifcbk_conv2d_fwd(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const vo
 int ifcbk_conv2d_fwd_affine(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y,
                             const float* scale, const float* shift, const void* residual, int ldr, int relu,
                             void* stream);
+/* ... and, where that activation feeds ONLY a 3x3 / stride-2 / unpadded max pool (inception Conv2d_2b_3x3 -> maxpool1), the pool as well:
+ * y_pooled [N, (P-3)/2+1, (Q-3)/2+1, ldp] = maxpool(act(conv(x,w)*scale[k] + shift[k])), bit-identical to ifcbk_conv2d_fwd_affine followed
+ * by ifcbk_maxpool_fwd, the activation is never stored.  Served for the shapes of the row-streaming kernel (3x3 / stride 1, 32 -> 64
+ * channels, bf16, Q <= 160): ..._ok returns 1, otherwise the caller runs the two calls.  Replaces [TV] `F.relu(bn(conv(x)))` +
+ * `F.max_pool2d(x, 3, 2)` of Inception3._forward in eval mode (reference call site neuston_models.py:94-103, 152-157).              */
+int ifcbk_conv2d_fwd_affine_maxpool_ok(const ifcbk_conv_desc*);
+int ifcbk_conv2d_fwd_affine_maxpool(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y_pooled, int ldp,
+                                    const float* scale, const float* shift, int relu, void* stream);
 /* Eval-mode sibling GEMM: ONE convolution whose d->K output channels belong to nseg (<= 4) consecutive segments with their own
  * destination tensors ys[s] (pixel stride ldys[s], ksegs[s] channels; sizes sum to d->K; d->ldy is ignored).  affine[s] = 1:
  * y = relu(conv * scale[k] + shift[k]) with the per-channel arrays indexed by the merged channel k (the folded BatchNorm of
@@ -343,7 +351,8 @@ enum {
     IFCBK_OP_DROPOUT,        /* p: x, mask (nullable), y; i[0] = n, i[1] = dtype; f[0] = scale; flags bit 0 accumulate           */
     IFCBK_OP_FLATTEN_CHW,    /* p: x, flat; i: N, HW, C, ldx | dtype << 32; flags bit 0 accumulate, bit 2 to_chw                 */
     IFCBK_OP_STEM_U8_FWD,    /* p: g, w_master, ab, y, bn_part (nullable), scale, shift (both NULL: raw + statistics); flags bit 2 relu */
-    IFCBK_OP_STEM_U8_WGRAD   /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
+    IFCBK_OP_STEM_U8_WGRAD,  /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
+    IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL  /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
 };
 typedef struct {
     int32_t kind;
