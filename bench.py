@@ -300,8 +300,8 @@ def layer_roofline(eng, pl, nsteps, hbm_tbps=6.29):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)      # 100 timed steps after 20 warm-up steps (2.3 s + 0.5 s)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE config: 256)')
     ap.add_argument('--classes', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
