@@ -381,14 +381,15 @@ def test_lane_count_does_not_change_the_result(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_prefetched_input_slots_equal_sequential_steps():
+@pytest.mark.parametrize('name,B', [('resnet18', 6), ('inception_v3', 3)])
+def test_prefetched_input_slots_equal_sequential_steps(name, B):
     """input pipelining (Engine.prefetch_begin / prefetch_end / use_prefetched, two input slots, preprocess of batch k+1 on a side
     stream beside step k): four training steps and an eval forward give bitwise the parameters, running statistics, loss and
     probabilities of the one-stream preprocess-then-step loop (reference: the DataLoader / Trainer loop, neuston_net.py:101-115)."""
     import numpy as np
     from ifcb_classifier_amd import graph
     from ifcb_classifier_amd.engine import Engine
-    B, NCLS = 6, 4
+    NCLS = 4            # (inception_v3: grey ROIs take the u8-plane stem -- plane, affine and plan are per input slot)
     rng = np.random.default_rng(7)
     batches = []
     for _ in range(5):
@@ -403,8 +404,10 @@ def test_prefetched_input_slots_equal_sequential_steps():
         batches.append((kw, torch.from_numpy(rng.integers(0, NCLS, B)).cuda()))
     engs = []
     for _ in range(2):
-        e = Engine(graph.build('resnet18', NCLS), 0, max_batch=B)
+        e = Engine(graph.build(name, NCLS), 0, max_batch=B)
         e.init_weights(seed=5)
+        if name == 'inception_v3':
+            e.external_mask = torch.ones(B, 2048, dtype=torch.uint8, device='cuda')
         engs.append(e)
     seq, pipe = engs
     for kw, y in batches[:4]:
@@ -432,6 +435,7 @@ def test_prefetched_input_slots_equal_sequential_steps():
     pipe.run(pl.softmax)
     torch.cuda.synchronize()
     assert {k[1] for k in pipe._plans} == {0, 1}                 # both input slots were used
+    assert {k[2] for k in pipe._plans} == ({'u8'} if name == 'inception_v3' else {'nhwc'})
     assert torch.equal(seq.P, pipe.P) and torch.equal(seq.RB, pipe.RB)
     assert torch.equal(seq.loss_sum, pipe.loss_sum)
     assert torch.equal(seq.probs[:B], pipe.probs[:B])
