@@ -7,8 +7,9 @@
 // and its weight gradient needs only  A[k,r,s] = sum dy[k] g[r,s]  and  B[k] = sum dy[k]:
 //     dw[k,r,s,c] = a_c A[k,r,s] + b_c B[k].
 // So the [B,S,S,8] input tensor (366 MB per batch of 256 at 299 px, written by the resize and read back 2.25 times by the GEMM
-// kernels) never exists: the resize writes the u8 plane (23 MB), these kernels read it through L1/L2.  Both are bound by the one
-// tensor they must move (the raw output / its gradient, 364 MB): HBM-bound, 9 taps x 32 channels of fp32 FMA per pixel is noise.
+// kernels) never exists: the resize writes the u8 plane (23 MB), these kernels read it through L1/L2.  The floor of both is the one
+// tensor they must move (the raw output / its gradient, 364 MB: 62 us as a plain fill); measured per batch of 256: forward 124 us,
+// weight gradient 125 us on the matrix cores (below), 152 / 213 us as vector FMAs -- against 317 / 180 us for the GEMM kernels.
 // Arithmetic: fp32 on the fp32 MASTER weights and exact u8 pixels (the GEMM path rounds x_c and w to bf16 first), outputs rounded
 // to the storage type; BatchNorm partial sums over the rounded outputs like every other conv epilogue.
 // Replaces aten::conv2d fwd / weight-grad of [TV] Inception3.Conv2d_1a_3x3 (reference call site neuston_models.py:66-68, 81-86).
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void stem_u8_fwd_kernel(StemArgs a) {
     T* y = (T*)a.y;
     for (int it = 0; it < PIXB / 64; it += UNR) {
         if (m0 + it * 64 >= a.M) break;
-        // (a dependent chain index -> bytes -> FMAs -> store per trip left the kernel latency bound at three waves per SIMD: 145 us for
-        // 364 MB; out-of-range trips load pixel M-1 and skip the store)
+        // (the loads of UNR trips go out together; out-of-range trips load pixel M-1 and skip the store.  This vector form serves fp32
+        // storage and rows narrower than 32 pixels; it is VALU-bound: 125 instructions per 16 pixels and wave)
         uint8_t gb[UNR][9];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
