@@ -9,15 +9,12 @@
 //
 // Geometry.  Wave w: group g = w >> 2 owns the pixel half [g*16*MT, (g+1)*16*MT) of the tile, column quarter wc = w & 3 owns
 // 16*TN channels: MT x TN accumulator tiles of 16x16 per wave (MT = 8 or 10: 256 / 320 pixels, TN = 2..4: 128..256 channels).
-// A K-tile (64 k) is consumed in NPH = MT/2 PHASES of two pixel tiles x TN channel tiles x 2 k-halves = 4*TN MFMAs.
 // A 320-pixel tile exists for the 17x17 maps: 256 images x 289 pixels = 73,984 rows are 289 tiles of 256 (a second, nearly
 // empty round on 256 CUs) but 232 tiles of 320 -- one round.
 //
-// LDS ring, in units the phases consume.  Pixel operand: 2*NPH slots of 64 rows x 128 B (32 rows of each group's half = what
-// ONE phase reads); slot of phase h = h mod 2*NPH; its 8 LDS-DMA pieces (1 KiB = 8 rows each) are issued by the 8 waves LA = 4
-// phases ahead.  Filter operand: two K-tile buffers of BN rows; a K-tile's TN*8 pieces are issued one per wave and phase,
-// LB = TN + 2 .. 3 phases ahead, and read into registers once, in the K-tile's first phase.  Every phase each wave issues its
-// 1-2 pieces, then waits with a COUNTED vmcnt that leaves the pieces of the last ~2.5 phases in flight, then meets the barrier.
+// A K-tile (64 k) is consumed in TWO phases of PM0 and PM1 = MT - PM0 pixel tiles (conv_pp2 below has the schedule); the pixel
+// operand lives in two slots per K-tile parity, the filter operand in two K-tile buffers, both filled by LDS-DMA pieces of 1 KiB
+// (8 rows of 128 B) that the waves issue in their load half-phase and wait for with a COUNTED vmcnt.
 //
 // Ordering (physical barriers are numbered; group 1 executes one extra barrier up front, group 0 one at the end):
 //   group 0:  load(g) | #2g | mfma(g) | #2g+1 | load(g+1) ...        group 1:  #2g | load(g) | #2g+1 | mfma(g) | #2g+2 ...
@@ -27,242 +24,20 @@
 //        fragments in registers (lgkmcnt(0)) right after #2g+1, the earliest writer (group 0 in load(g+2)) starts after #2g+3.
 // Fragment reads are inline-asm ds_read_b128 (the compiler orders every LDS access it can see behind ALL pending LDS-DMA,
 // which would drain the ring every phase); their lgkmcnt(0) sits behind the barrier, in front of the MFMA cluster.
+//
+// (Round 2 also had a finer-grained form, `conv_big`: MT/2 phases of 4*TN MFMAs per K-tile with a 2*NPH-slot ring.  It was the
+// kernel the measurements quoted below were first made on, ran at the same speed as the two-phase form and was removed in
+// round 3; DESIGN.md 5.4 keeps its numbers.)
 #include "conv_common.h"
 #include <stdlib.h>
 #include <string.h>
 
 namespace {
 
-template <int TN, int MT>
-struct BigCfg {
-    static constexpr int NPH = MT / 2;               // phases per K-tile
-    static constexpr int LA = 4;                     // pixel pieces: issued LA phases ahead of the phase that reads them
-    static constexpr int LB = TN + 2;                // filter pieces of a K-tile: piece p issued at (K-tile start) - LB + p
-    static_assert(MT % 2 == 0 && NPH >= 4 && LB <= 2 * NPH - 2 && TN <= NPH, "ring too shallow for this tile");
-    // loads one wave issues in phase x (any integer): its pixel piece + a filter piece in TN of the NPH phases
-    static constexpr int nld(int x) {
-        x = ((x % NPH) + NPH) % NPH;
-        return 1 + (((x + LB) % NPH) < TN ? 1 : 0);
-    }
-    // vmcnt at the end of load(J): everything read in load(J+1) has landed.  Pixel piece of phase J+1: issued in phase
-    // J+1-LA as the LAST load of that phase.  Filter pieces (needed when J+1 starts a K-tile): the last one was issued in
-    // phase J-2 as the FIRST load of that phase.
-    static constexpr int vm(int J) {
-        int a = 0;
-        for (int x = J + 2 - LA; x <= J; ++x) a += nld(x);
-        if ((J + 1) % NPH == 0) {
-            int b = 1 + nld(J - 1) + nld(J);
-            if (b < a) a = b;
-        }
-        return a;
-    }
-};
-
 #define BIG_DSREAD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
 
-template <int TN, int MT, int MODE>
-__global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
-    typedef bf16_t T;
-    typedef BigCfg<TN, MT> Cfg;
-    constexpr int ES = 2, CE = 8, BK = 64;
-    constexpr int NPH = Cfg::NPH, LA = Cfg::LA, LB = Cfg::LB;
-    constexpr int HM = 16 * MT, BM = 2 * HM, BN = 64 * TN;
-    constexpr int NSLOT = 2 * NPH;
-    constexpr int ASLOT = 64 * BK * ES;               // bytes per pixel-operand slot
-    constexpr int BBUF = BN * BK * ES;                // bytes per filter K-tile buffer
-    constexpr int A_BYTES = NSLOT * ASLOT, RING_BYTES = A_BYTES + 2 * BBUF;
-    constexpr int LDC = BN + CE;
-    constexpr int CT_BYTES = BM * LDC * ES + 8 * BN * 2 * 4;
-    constexpr int SMEM_BYTES = RING_BYTES > CT_BYTES ? RING_BYTES : CT_BYTES;
-    static_assert(SMEM_BYTES <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-    T* sC = reinterpret_cast<T*>(smem);
-    float* sRed = reinterpret_cast<float*>(smem + BM * LDC * ES);
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = wave >> 2, wc = wave & 3;
-    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
-    const int mtile = bid / a.tilesN, ntile = bid - mtile * a.tilesN;
-    const int m0 = mtile * BM, n0 = ntile * BN;
-
-    // ---- LDS-DMA roles (as conv_igemm): one wave-instruction fills 8 tile rows; lane -> (row l>>3, physical chunk l&7);
-    // the XOR swizzle is applied on the source side; out-of-range offsets read zeros through the buffer descriptor
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.wbytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int lrow8 = lane >> 3;
-    const int csrc = (lane & 7) ^ lrow8;
-    // pixel rows this lane gathers: one per phase-of-a-K-tile jp (slot rows 8*wave .. 8*wave+7 = this wave's own group)
-    int off0[NPH], bh[NPH], bw[NPH];
-    unsigned va[NPH];
-#pragma unroll
-    for (int jp = 0; jp < NPH; ++jp) {
-        const int m = m0 + grp * HM + 32 * jp + 8 * wc + lrow8;
-        const bool rv = m < a.M;
-        const int mm = rv ? m : 0;
-        const int n = (int)fdiv((uint32_t)mm, a.fPQ);
-        const int rem = mm - n * a.PQ;
-        const int p = (int)fdiv((uint32_t)rem, a.fQ);
-        const int q = rem - p * a.Q;
-        bh[jp] = rv ? p * a.ostr_h + a.base_h : -(1 << 24);
-        bw[jp] = q * a.ostr_w + a.base_w;
-        off0[jp] = ((n * a.H + bh[jp]) * a.W + bw[jp]) * a.ldx;
-        va[jp] = bh[jp] >= 0 ? (unsigned)(off0[jp] + csrc * CE) * (unsigned)ES : OOB;
-    }
-    int kc = csrc * CE, kr = 0, ks = 0;
-    while (kc >= a.C) {
-        kc -= a.C;
-        if (++ks == a.S) { ks = 0; ++kr; }
-    }
-    int tapoff = (kr * a.W + ks) * a.ldx + kc;
-    int ktA = 0;                                       // K-tile of the next pixel pieces
-    unsigned woff[TN];
-#pragma unroll
-    for (int p = 0; p < TN; ++p) {
-        const int n = n0 + p * 64 + wave * 8 + lrow8;
-        woff[p] = n < a.K ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
-    }
-    const int nk = (a.Kg + BK - 1) / BK;
-    const int rowstep = a.W * a.ldx, colwrap = a.S * a.ldx;
-    const bool plain = a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0;
-    const bool ktail_ok = (nk - 1) * BK + csrc * CE < a.Kg;
-
-    // the pixel piece of K-tile ktA, phase-in-tile JP, into slot (ktA & 1) * NPH + JP (rows 8*wave..)
-#define BIG_ISSUE_A(JP)                                                                                                   \
-    {                                                                                                                     \
-        unsigned char* dst = smem + ((ktA & 1) * NPH + (JP)) * ASLOT + wave * 8 * BK * ES;                                \
-        if (plain) {                                                                                                      \
-            const bool cut = ktA >= nk || (ktA == nk - 1 && !ktail_ok);                                                   \
-            lds_dma16(rsA, (lptr_t)dst, cut ? OOB : va[JP], ktA * 128);                                                   \
-        } else {                                                                                                          \
-            const int hr = bh[JP] + kr, wr = bw[JP] + ks;                                                                 \
-            const bool v = kr < a.R && (unsigned)hr < (unsigned)a.H && (unsigned)wr < (unsigned)a.W;                      \
-            const unsigned voff = v ? (unsigned)(off0[JP] + tapoff) * (unsigned)ES : OOB;                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst, 16, voff, 0, 0, 0);                                \
-        }                                                                                                                 \
-        if ((JP) == NPH - 1) {                                                                                            \
-            ++ktA;                                                                                                        \
-            if (!plain) {                                                                                                 \
-                kc += BK;                                                                                                 \
-                tapoff += BK;                                                                                             \
-                while (kc >= a.C) {                                                                                       \
-                    kc -= a.C;                                                                                            \
-                    tapoff += a.ldx - a.C;                                                                                \
-                    if (++ks == a.S) { ks = 0; ++kr; tapoff += rowstep - colwrap; }                                       \
-                }                                                                                                         \
-            }                                                                                                             \
-        }                                                                                                                 \
-    }
-    // filter piece P (rows 64*P + 8*wave ..) of K-tile KT (chunks past Kg read the next row's head: the pixel operand is zero there)
-#define BIG_ISSUE_B(P, KT)                                                                                                \
-    {                                                                                                                     \
-        unsigned char* dst = smem + A_BYTES + ((KT) & 1) * BBUF + ((P) * 64 + wave * 8) * BK * ES;                         \
-        /* K-tiles past the end are issued too (the counted waits assume a fixed number of pieces per phase) but read nothing: \
-           the scalar offset is not part of the descriptor's range check */                                               \
-        lds_dma16(rsB, (lptr_t)dst, (KT) < nk ? woff[P] : OOB, (KT) * 128);                                               \
-    }
-    // virtual phase G < 0: only issues what the steady state would have issued then
-#define BIG_PROLOGUE(G)                                                                                                   \
-    if constexpr (-(G) <= (LA > LB ? LA : LB)) {                                                                          \
-        if constexpr ((G) + LB >= 0 && (((G) + LB) % NPH) < TN) BIG_ISSUE_B(((G) + LB) % NPH, ((G) + LB) / NPH)           \
-        if constexpr ((G) + LA >= 0) BIG_ISSUE_A(((G) + LA) % NPH)                                                        \
-    }
-    BIG_PROLOGUE(-8) BIG_PROLOGUE(-7) BIG_PROLOGUE(-6) BIG_PROLOGUE(-5) BIG_PROLOGUE(-4) BIG_PROLOGUE(-3) BIG_PROLOGUE(-2) BIG_PROLOGUE(-1)
-    static_assert(LA <= 8 && LB <= 8, "prologue depth");
-
-    // ---- fragment addresses (LDS bytes): row = lane & 15 of a 16-row tile, 16-byte chunk (kk*4 + lane>>4) ^ (row & 7)
-    const int frow = lane & 15, fchunk = lane >> 4;
-    unsigned faA[2], faB[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int ph = ((kk * 4 + fchunk) ^ (frow & 7)) * 16;
-        faA[kk] = (unsigned)(size_t)(lptr_t)(smem + (grp * 32 + frow) * BK * ES + ph);
-        faB[kk] = (unsigned)(size_t)(lptr_t)(smem + A_BYTES + (wc * 16 * TN + frow) * BK * ES + ph);
-    }
-
-    f32x4_t acc[MT][TN];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // what phase 0 reads (pixel slot 0, the filter tile 0) has landed in every wave's share, and every wave knows it
-    wait_vmcnt<Cfg::vm(-1)>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
-
-    bf16x8_t fb[TN][2];
-#define BIG_PHASE(J)                                                                                                      \
-    if constexpr ((J) < NPH) {                                                                                            \
-        bf16x8_t fa[2][2];                                                                                                \
-        if constexpr ((J) == 0) {                                                                                         \
-            _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) {                                                           \
-                BIG_DSREAD(fb[nt][0], bB0, nt * 16 * BK * ES);                                                            \
-                BIG_DSREAD(fb[nt][1], bB1, nt * 16 * BK * ES);                                                            \
-            }                                                                                                             \
-        }                                                                                                                 \
-        BIG_DSREAD(fa[0][0], bA0, (J) * ASLOT);                                                                           \
-        BIG_DSREAD(fa[0][1], bA1, (J) * ASLOT);                                                                           \
-        BIG_DSREAD(fa[1][0], bA0, (J) * ASLOT + 16 * BK * ES);                                                            \
-        BIG_DSREAD(fa[1][1], bA1, (J) * ASLOT + 16 * BK * ES);                                                            \
-        if constexpr ((((J) + LB) % NPH) < TN) BIG_ISSUE_B(((J) + LB) % NPH, kt + ((J) + LB) / NPH)                       \
-        BIG_ISSUE_A(((J) + LA) % NPH)                                                                                     \
-        wait_vmcnt<Cfg::vm(J)>();                                                                                         \
-        __builtin_amdgcn_s_barrier();                                                                                     \
-        if constexpr ((J) == 0) {                                                                                         \
-            if constexpr (TN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
-            if constexpr (TN == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
-            if constexpr (TN == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])); \
-        } else {                                                                                                          \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]));         \
-        }                                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
-        __builtin_amdgcn_s_setprio(1);                                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                  \
-            _Pragma("unroll") for (int ml = 0; ml < 2; ++ml)                                                              \
-                _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                         \
-                    acc[2 * (J) + ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[2 * (J) + ml][nt], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                \
-        __builtin_amdgcn_s_barrier();                                                                                     \
-        asm volatile("" ::: "memory");                                                                                    \
-    }
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned par = (unsigned)(kt & 1);
-        const unsigned bA0 = faA[0] + par * (NPH * ASLOT), bA1 = faA[1] + par * (NPH * ASLOT);
-        const unsigned bB0 = faB[0] + par * BBUF, bB1 = faB[1] + par * BBUF;
-        BIG_PHASE(0) BIG_PHASE(1) BIG_PHASE(2) BIG_PHASE(3) BIG_PHASE(4)
-    }
-    static_assert(NPH <= 5, "phase macro expansion");
-#undef BIG_PHASE
-#undef BIG_PROLOGUE
-#undef BIG_ISSUE_A
-#undef BIG_ISSUE_B
-    if (grp == 0) __builtin_amdgcn_s_barrier();        // both groups have executed the same number of barriers
-    wait_vmcnt<0>();                                   // the tail's dummy pieces (K-tiles >= nk) have landed too
-    __syncthreads();                                   // the ring is dead: the epilogue reuses it as the C tile
-
-    // ---- epilogue: acc -> storage-type C tile in LDS (a lane holds 4 consecutive channels of one pixel per 16x16 tile)
-    {
-        const int g4 = lane >> 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < TN; ++nt) {
-                const int m = grp * HM + mt * 16 + frow;
-                const int n = wc * (16 * TN) + nt * 16 + 4 * g4;
-                Mma<T>::pack4(sC + m * LDC + n, acc[mt][nt]);
-            }
-    }
-    __syncthreads();
-    conv_epilogue_store<T, BM, BN, 512, MODE>(a, sC, sRed, t, lane, wave, m0, n0, mtile);
-}
-
-// ---------------------------------------------------------------- two long phases per K-tile
-// Same ping-pong, coarser grain.  Measured on conv_big (loads dropped through zero-record descriptors): the operand traffic is
+// ---------------------------------------------------------------- the kernel: two long phases per K-tile
+// Measured on the finer-grained predecessor (loads dropped through zero-record descriptors): the operand traffic is
 // NOT what bounds it (6e 7x1: 52.8 us -> 48.0 us with both operands dropped) -- the half-phase between two barriers is as long
 // as the LOAD side needs (fragment reads, piece issue, address VALU, waits: ~400 cycles) while the MFMA side has only 4*TN
 // MFMAs (192-256 cycles) to set against it.  Here a K-tile has TWO phases, of PM0 and PM1 = MT - PM0 pixel tiles: 2*PM*TN
@@ -270,7 +45,7 @@ __global__ __launch_bounds__(512) void conv_big(ConvArgs a) {
 //   phase 2T   (even): reads the filter fragments of K-tile T and the pixel tiles [0, PM0); issues the EVEN pixel slot and the
 //                      filter pieces of K-tile T+1 (PM0/2 + TN pieces per wave); then vmcnt(PM0/2 + TN): the odd slot of T is in
 //   phase 2T+1 (odd):  reads pixel tiles [PM0, MT); issues the ODD pixel slot of K-tile T+1 (PM1/2 pieces); then vmcnt(PM1/2)
-// Slots are double-buffered by K-tile parity; every slot is re-filled two phases after its last read (WAR rule of conv_big).
+// Slots are double-buffered by K-tile parity; every slot is re-filled two phases after its last read (the WAR rule above).
 // timing experiment (built with `make EXTRA=-DIFCBK_EXPERIMENT_FRAG_AFFINE`, run with IFCBK_DEBUG_DROP=f; wrong results): what BatchNorm-apply + ReLU on the pixel fragment AFTER its LDS read
 // would cost -- the producer's activation never written, the consumer normalises what it multiplies.
 // Optimistic: scale / shift are lane constants here; a real version adds two LDS reads per fragment for the per-channel pair
@@ -593,15 +368,9 @@ void launch_big(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 4>), grid, block, 0, st, a);
         return;
     }
-    if (big_force("IFCBK_CONV_BIG_NPH") != 5) {          // default: two long phases per K-tile; 5 = the fine-grained conv_big
-        if (a.bs_tab) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 5>), grid, block, 0, st, a);
-        else if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 0>), grid, block, 0, st, a);
-        return;
-    }
-    if (a.bs_tab) hipLaunchKernelGGL((conv_big<TN, MT, 5>), grid, block, 0, st, a);
-    else if (a.bs_raw) hipLaunchKernelGGL((conv_big<TN, MT, 3>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_big<TN, MT, 0>), grid, block, 0, st, a);
+    if (a.bs_tab) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 5>), grid, block, 0, st, a);
+    else if (a.bs_raw) hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 3>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_pp2<TN, MT, PM0, 0>), grid, block, 0, st, a);
 }
 
 }  // namespace

@@ -333,12 +333,8 @@ int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* 
     a.tiles = cdiv(d->K, 32 * kh) * a.tilesJ;
     a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
     const dim3 grid((unsigned)(a.tiles * nsplit)), block(512);
-    const char* e = getenv("IFCBK_WGRAD_PP_DM");
-    const int dm = e ? atoi(e) : 0;
-    if (kh == 4 && dm) hipLaunchKernelGGL((conv_wgrad_pp<4, 1>), grid, block, 0, st, a);
-    else if (kh == 5 && dm) hipLaunchKernelGGL((conv_wgrad_pp<5, 1>), grid, block, 0, st, a);
-    else if (kh == 6 && dm) hipLaunchKernelGGL((conv_wgrad_pp<6, 1>), grid, block, 0, st, a);
-    else if (kh == 4) hipLaunchKernelGGL((conv_wgrad_pp<4, 0>), grid, block, 0, st, a);
+    // (DM = 1 -- the pieces issued from inside the MFMA cluster -- was 5-10 % slower everywhere and is no longer instantiated)
+    if (kh == 4) hipLaunchKernelGGL((conv_wgrad_pp<4, 0>), grid, block, 0, st, a);
     else if (kh == 5) hipLaunchKernelGGL((conv_wgrad_pp<5, 0>), grid, block, 0, st, a);
     else if (kh == 6) hipLaunchKernelGGL((conv_wgrad_pp<6, 0>), grid, block, 0, st, a);
     else IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_pp: kh=%d", kh);

@@ -493,8 +493,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int mt = 0, cols = 0;
             ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
             if (mt < 0) {
-                const char* dm = getenv("IFCBK_WGRAD_PP_DM");          // the name rocprofv3 lists: <KH, DM>
-                snprintf(name, cap, "conv_wgrad_pp<%d, %d>", -mt, dm && atoi(dm) ? 1 : 0);
+                snprintf(name, cap, "conv_wgrad_pp<%d, 0>", -mt);          // the name rocprofv3 lists: <KH, DM>
             }
             else if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
             else if (mt == 0) snprintf(name, cap, "conv_wgrad_stem");

@@ -16,7 +16,7 @@ from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
 # environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
-_DISPATCH_SWITCHES = ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_BIG_NPH', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+_DISPATCH_SWITCHES = ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
                       'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
                       'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_PP_DM', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
 
@@ -750,13 +750,10 @@ class Engine:
             if m.kind != 'head':
                 producers.setdefault(m.y.buf.id, []).append(m)
 
-        # Which chain gets which lane.  Default 'rr': chains in order of appearance -- lane 0 (the caller's stream, where the
-        # sibling GEMMs and their gradients run) takes the light 1x1 branch, the heavy chains land on lanes 1 and 2.
-        # IFCBK_LANE_ORDER=long puts the HEAVIEST chain of every block on lane 0 so that the critical path continues on one
-        # stream instead of across a lane-to-lane event wait (the kernel trace shows ~60 idle gaps of 15-25 us per step there).
-        # Measured: 25.40 vs 23.96 ms per train step, 6.17 vs 5.96 ms per eval forward -- lane 0 then serialises the block's
-        # sibling GEMM, its heaviest chain and the next sibling GEMM while the other lanes run dry.  Kept as a switch, off.
-        lane_order = os.environ.get('IFCBK_LANE_ORDER', 'rr')
+        # Which chain gets which lane: chains in order of appearance -- lane 0 (the caller's stream, where the sibling GEMMs and their
+        # gradients run) takes the light 1x1 branch, the heavy chains land on lanes 1 and 2.  Putting the HEAVIEST chain of every
+        # block on lane 0 (round 2) or rotating the lanes so that a block's GEMM follows the previous block's heaviest chain on the
+        # same stream (round 3) both lose ~1 ms per step: the event wait they save is cheaper than what they serialise.
 
         def follows_of():
             f = {}
@@ -769,28 +766,20 @@ class Engine:
                     f[m] = prods[0]
             return f
 
-        def node_weight(m):
-            if m.kind in ('conv', 'cb'):
-                return float(m.P * m.Q * m.K * m.R * m.S * m.x.C) + 4.0 * m.P * m.Q * m.K * 64
-            return 4.0 * m.y.H * m.y.W * m.y.C * 64          # memory-bound nodes: bytes, on the conv's MAC scale
-
         def assign_lanes(nl):
             follows = follows_of()
-            head_of, weight = {}, {}
+            head_of = {}
             for m in net.nodes:                       # forward order: a follower's producer is already resolved
                 if m.aux or m.kind == 'head':
                     continue
-                h = head_of[follows[m]] if m in follows and follows[m] in head_of else m
-                head_of[m] = h
-                weight[h] = weight.get(h, 0.0) + node_weight(m)
+                head_of[m] = head_of[follows[m]] if m in follows and follows[m] in head_of else m
             by_tensor = {}
             for m in net.nodes:
                 if not m.aux and m.kind != 'head' and head_of.get(m) is m:
                     by_tensor.setdefault(m.x.buf.id, []).append(m)
             rank = {}
             for heads in by_tensor.values():
-                order = sorted(heads, key=lambda h: -weight[h]) if lane_order == 'long' else heads
-                for k, h in enumerate(order):
+                for k, h in enumerate(heads):
                     rank[h] = k
             lanes = {}
             for m in net.nodes:

@@ -75,9 +75,8 @@ for name in which:
     res = {}
     for mode in modes:
         outs = {}
-        for big in ('0', '1', '5'):
-            os.environ['IFCBK_CONV_BIG'] = '0' if big == '0' else '1'
-            os.environ['IFCBK_CONV_BIG_NPH'] = '5' if big == '5' else '0'
+        for big in ('0', '1'):
+            os.environ['IFCBK_CONV_BIG'] = big
             kn = kname(d, _lib.OP_CONV_FWD if mode == 'fwd' else _lib.OP_CONV_DGRAD)
             if mode == 'fwd':
                 y = torch.full((N, P, Q, K), float('nan'), device='cuda', dtype=torch.bfloat16)
@@ -95,25 +94,24 @@ for name in which:
                 run(); torch.cuda.synchronize()
                 outs[big] = (kn, run, rel(dx.float(), ref_dx), 0.0, dx)
         # interleaved timing rounds
-        ms = {'0': [], '1': [], '5': []}
+        ms = {'0': [], '1': []}
         for r in range(reps):
-            for big in ('0', '1', '5'):
-                os.environ['IFCBK_CONV_BIG'] = '0' if big == '0' else '1'
-                os.environ['IFCBK_CONV_BIG_NPH'] = '5' if big == '5' else '0'
+            for big in ('0', '1'):
+                os.environ['IFCBK_CONV_BIG'] = big
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
                     outs[big][1]()
                 e1.record(); torch.cuda.synchronize()
                 ms[big].append(e0.elapsed_time(e1) / 3)
-        m0, m1, m5 = min(ms['0']), min(ms['1']), min(ms['5'])
+        m0, m1 = min(ms['0']), min(ms['1'])
         same = outs['0'][0] == outs['1'][0]
         cross = rel(outs['1'][4].float(), outs['0'][4].float())            # new vs old kernel directly
         if not (outs['1'][2] < 5e-3) and cross < 3e-3 and not (outs['0'][2] < 5e-3):
             outs['1'] = outs['1'][:2] + (cross,) + outs['1'][3:]              # the torch reference is off for this shape: both kernels agree
-        print('%-9s %-5s old %-38s %7.3f ms %5.0f TF | pp2 %-18s %7.3f ms %5.0f TF x%.2f | 5ph %7.3f ms %5.0f TF | err old %.1e new %.1e stat %.1e %s'
+        print('%-9s %-5s old %-38s %7.3f ms %5.0f TF | pp2 %-18s %7.3f ms %5.0f TF x%.2f | err old %.1e new %.1e stat %.1e %s'
               % (name, mode, outs['0'][0], m0, flops / m0 / 1e9, '(same)' if same else outs['1'][0], m1, flops / m1 / 1e9, m0 / m1,
-                 m5, flops / m5 / 1e9, outs['0'][2], outs['1'][2], outs['1'][3], 'OK' if outs['1'][2] < 5e-3 and outs['1'][3] < 1e-4 else 'BAD'), flush=True)
+                 outs['0'][2], outs['1'][2], outs['1'][3], 'OK' if outs['1'][2] < 5e-3 and outs['1'][3] < 1e-4 else 'BAD'), flush=True)
         bad += 0 if (outs['1'][2] < 5e-3 and outs['1'][3] < 1e-4) else 1
         t = tot.setdefault(mode, [0.0, 0.0, 0.0])
         t[0] += m0; t[1] += m1; t[2] += flops

@@ -40,7 +40,7 @@ def _kname(ctx, d, kind, flags=0, residual=False):
 @pytest.fixture
 def forced(monkeypatch):
     def set_(**kw):
-        for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_BIG_NPH', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
+        for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
                   'IFCBK_CONV_FLAT'):
             monkeypatch.delenv(k, raising=False)
         for k, v in kw.items():
