@@ -2,6 +2,7 @@
 """Headline benchmark: inception_v3 100-class bf16 TRAIN on synthetic IFCB ROIs (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          # starts its N ranks itself (self_launch below), or, equivalently,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -297,6 +298,98 @@ def layer_roofline(eng, pl, nsteps, hbm_tbps=6.29):
             'note': 'survey pass (every op bracketed, one lane, each kernel alone on the GPU); bound = min(2.5 PF, AI x 6.29 TB/s)'}
 
 
+def launch_argv(n, argv, port):
+    """the command that starts the N ranks of this benchmark: what the driver itself runs for N > 1 (one process per GPU over
+    RCCL).  The reference gets its N processes the same way without a launcher on the command line: Lightning's ddp_spawn from
+    ``gpus=len(args.gpus)`` (neuston_net.py:101-107,430-432)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched the
+    GPU and never will: no torch.cuda call, no library load -- nothing re-execs a process that initialised HIP), relay rank 0's
+    JSON line unchanged as the LAST stdout line, everything else to stderr, and return the children's exit code."""
+    import subprocess
+    cmd = launch_argv(n, argv, free_port())
+    print('[bench] --gpus %d without WORLD_SIZE: starting the ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith('{') and '"metric"' in t:
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)
+        sys.stderr.flush()
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print('[bench] the ranks exited 0 but rank 0 printed no result line', file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def rehearse(args, rank, world):
+    """IFCBK_BENCH_REHEARSE=1: the N > 1 control flow WITHOUT a GPU -- rendezvous on gloo, the engine's real backward op list and
+    bucket plan (Engine(plan_only=True)), the configured bucket exchange (IFCBK_DP_EXCHANGE) over the real bucket sizes on CPU
+    tensors, the barrier / max-over-ranks timing and the rank-0 line.  Not a measurement: `value` is null and the line says so.
+    What the CPU test of the self-launch path runs (tests/test_bench_launch_cpu.py)."""
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.dp import make_exchange, run_overlapped
+    from ifcb_classifier_amd.engine import Engine
+    torch.set_num_threads(2)
+    eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), max_batch=2, plan_only=True)
+    pl = eng.plan(2)
+    segs = eng.ddp_segments(pl)
+    exchange, mode = make_exchange(dist)
+    eng.G.fill_(float(rank + 1))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, min(args.steps, 3))):
+        eng.G.fill_(float(rank + 1))
+        run_overlapped(segs, lambda seg: None, eng.G, exchange)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    want = world * (world + 1) / 2.0
+    ok = bool((eng.G == want).all())
+    devs = [None] * world
+    dist.all_gather_object(devs, 'cpu:%d' % rank)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'train images/sec, inception_v3 299^2 IFCB ROIs', 'value': None, 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'REHEARSAL on CPU (IFCBK_BENCH_REHEARSE=1): rendezvous, bucket plan and exchange only, no GPU work',
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'rank_devices': devs,
+                       'exchange': mode, 'buckets': [int(s[3] - s[2]) for s in segs]},
+            'rehearsal': True, 'exchange_sums_ok': ok, 'cpu_baseline': None,
+            'cpu_baseline_reason': 'rehearsal: nothing is measured'}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -315,12 +408,16 @@ def main():
                     'launch for launch with the per-kernel HIP-event times')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # started the way the driver starts the N = 1 run, with --gpus N: become the launcher (before any GPU call)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: start %d ranks (or none: bench.py starts them itself)' % (args.gpus, world, args.gpus))
+    if os.environ.get('IFCBK_BENCH_REHEARSE', '0') != '0':
+        raise SystemExit(rehearse(args, rank, world))
     if 'IFCBK_BENCH_DEVICE' in os.environ:      # rehearsal of the N>1 path on a one-GPU box: every rank on the same device
         local = int(os.environ['IFCBK_BENCH_DEVICE'])
     torch.cuda.set_device(local)
@@ -349,8 +446,17 @@ def main():
     do_survey = (not args.no_events) and args.steps <= 256
     use_ev = do_survey and world == 1        # events in the timed region: single-GPU runs only (the N>1 step is several programs)
 
-    def allred(t):
-        return dist.all_reduce(t, async_op=True)
+    allred, exchange_name = None, None
+    if world > 1:
+        from ifcb_classifier_amd.dp import make_exchange
+        allred, exchange_name = make_exchange(dist)      # IFCBK_DP_EXCHANGE=allreduce|rsag
+    # exposed part of the exchange: an event pair around the waits behind the last backward segment, every timed step
+    ex_events = []
+
+    def ex_mark(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        ex_events.append(ev)
 
     # input pipelining (the product's Trainer does the same, neuston_net.Trainer._lookahead): the on-GPU preprocessing of batch
     # k+1 runs on a side stream into the engine's other input slot while step k computes.  Every timed step still contains
@@ -358,6 +464,7 @@ def main():
     # a fifth stream next to the four program lanes costs 0.5 ms per step on this runtime (4 hardware queues per process;
     # GPU_MAX_HW_QUEUES=8 is far worse) -- measured 24.40 vs 23.92 ms.  What it buys is in `pcie_inclusive` below.
     pipelined = os.environ.get('IFCBK_BENCH_PIPELINE', '0') != '0'
+    timing_on = [False]
     for tb in eng.tgt_bufs:
         tb[:B].copy_(eng.tgt_bufs[0][:B])
 
@@ -377,7 +484,7 @@ def main():
         else:
             eng.load_rois(**rois)
         if world > 1:
-            eng.train_step_ddp(B, world, allred)
+            eng.train_step_ddp(B, world, allred, mark=ex_mark if timing_on[0] else None)
         else:
             eng.train_step(B, ev_slot=k, ev_arr=None if ev_arrs is None else ev_arrs[eng.in_slot])
         if pipelined and not stage_first:
@@ -448,6 +555,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    timing_on[0] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k if use_ev else None, ev_dom)
@@ -456,10 +564,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timing_on[0] = False
+    exposed_ms, rank_devices = None, [local]
     if world > 1:
         tt = torch.tensor([dt], device=eng.dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        exposed_ms = sum(a.elapsed_time(b) for a, b in zip(ex_events[0::2], ex_events[1::2])) / max(1, len(ex_events) // 2)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, int(local))
     loss = float(eng.loss.item())
 
     # secondary number (BASELINE metric is "train + infer"): RUN-mode inference on the same ROIs -- on-GPU
@@ -542,6 +655,7 @@ def main():
             'config': {'workload': 'inception_v3 100-class bf16 TRAIN, batch %d per GPU, synthetic u8 ROIs h,w~U{32..299} '
                                    'resized on-GPU to 299x299 (BASELINE.json configs[1])' % B,
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'program_lanes': eng.NL, 'optimizer': 'adam lr=1e-3',
+                       'rank_devices': rank_devices,
                        'loss': 'CE + 0.4*CE_aux',
                        'input_pipeline': ('preprocess of batch k+1 on a side stream beside step k (two input slots); one preprocess + '
                                           'one train step per timed step') if pipelined else 'preprocess then step on one stream'},
@@ -549,6 +663,16 @@ def main():
             'mfma_frac_whole_step': round(ips * TRAIN_GFLOP_PER_IMG * 1e-3 / (world * MFMA_BF16_PEAK_TFLOPS), 4),
             'final_loss': round(loss, 4),
         }
+        if world > 1:
+            segs = eng.ddp_segments(pl)
+            out['exchange'] = {'algorithm': exchange_name, 'backend': dist.get_backend(), 'buckets': len(segs),
+                               'bucket_bytes': [int(4 * (sg[3] - sg[2])) for sg in segs],
+                               'exposed_ms_per_step': round(exposed_ms, 4),
+                               'note': 'fp32 sum of the flat gradient, one bucket per backward segment, launched behind the segment '
+                                       'that completes it; exposed = HIP-event pair around the waits behind the last segment, rank 0, '
+                                       'mean over the timed steps (IFCBK_DP_EXCHANGE=allreduce|rsag)'}
+            out['cpu_baseline'] = None
+            out['cpu_baseline_reason'] = 'N > 1: the CPU reference is timed on rank 0 of the N = 1 run only (bench contract)'
         if pcie:
             out['pcie_inclusive'] = pcie
         if n_inf:

@@ -7,7 +7,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('IFCBK_LIB') or os.path.join(_HERE, 'libifcbk.so')     # IFCBK_LIB: another build of the library (same-box A/B of kernel variants)
+LIB_PATH = os.path.join(_HERE, 'libifcbk.so')
+if os.environ.get('IFCBK_LIB'):
+    # another build of the library for a same-box A/B of kernel variants: an explicit ABSOLUTE path to an existing file, nothing
+    # is searched for; the product never sets it
+    _alt = os.environ['IFCBK_LIB']
+    if not (os.path.isabs(_alt) and os.path.isfile(_alt)):
+        raise RuntimeError('IFCBK_LIB must be the absolute path of an existing libifcbk build, got %r' % _alt)
+    import sys as _sys
+    print('[ifcbk] IFCBK_LIB: loading %s instead of the in-tree library' % _alt, file=_sys.stderr)
+    LIB_PATH = _alt
 
 BF16, F32 = 0, 1
 
@@ -16,14 +25,15 @@ BF16, F32 = 0, 1
  OP_SOFTMAX_XENT, OP_SOFTMAX, OP_ADAM, OP_MEMSET, OP_COPY2D, OP_DROPOUT_MASK, OP_CONV_FWD_AFFINE,
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
  OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD, OP_CONV_DGRAD_BNSTAT_TAB,
- OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD, OP_CONV_FWD_AFFINE_MAXPOOL) = range(1, 38)
+ OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD, OP_CONV_FWD_AFFINE_MAXPOOL,
+ OP_STEP_COUNTERS) = range(1, 39)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
             24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd', 31: 'conv_dgrad',
-            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine'}
+            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine', 38: 'step_counters'}
 
 
 class ConvDesc(C.Structure):
@@ -124,6 +134,7 @@ _PROTOS = {
     'ifcbk_flatten_chw': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'ifcbk_softmax_xent': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp]),
     'ifcbk_softmax': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'ifcbk_step_counters': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     'ifcbk_adam_flat': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _f, _i, _f, _vp]),
     'ifcbk_sgd_flat': (_i, [_vp, _vp, _vp, _vp, C.c_int64, _f, _f, _f, _f, _vp]),
     'ifcbk_roi_preprocess': (_i, [_vp, C.POINTER(RoiDesc), _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

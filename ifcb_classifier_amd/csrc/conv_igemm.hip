@@ -36,7 +36,6 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm(ConvArgs a) {
     constexpr int JB = (NT * 4 + NW - 1) / NW;         // B-tile LDS-DMA instructions per wave per tile
     constexpr int G = 4 + JB;                          // LDS-DMA instructions per wave per tile
     constexpr int D = NSTAGE - 1;                      // prefetch distance (tiles)
-    constexpr int CPR = BN / CE;                       // 16-byte chunks per output row
     constexpr int LDC = BN + CE;                       // C-tile row stride (elements)
     constexpr int STAGE = (BM + BN) * BK;              // elements per pipeline stage
     constexpr int STAGE_BYTES = NSTAGE * STAGE * ES;

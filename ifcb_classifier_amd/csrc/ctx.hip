@@ -211,6 +211,8 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
         case IFCBK_OP_FLATTEN_CHW:
             return ifcbk_flatten_chw(c, (int)o->i[0], (int)o->i[1], (int)o->i[2], (int)(o->i[3] >> 32), p[0], (int)(o->i[3] & 0xffffffff),
                                      p[1], (o->flags >> 2) & 1, acc, st);
+        case IFCBK_OP_STEP_COUNTERS:
+            return ifcbk_step_counters(c, (int64_t*)p[0], (int)o->i[0], (float*)p[1], (const float*)p[2], st);
         case IFCBK_OP_DROPOUT_MASK:
             return ifcbk_dropout_mask(c, (uint8_t*)p[0], o->i[0], o->f[0], (uint64_t)o->i[1], (uint64_t)o->i[2], st);
         default: IFCBK_FAIL(c, IFCBK_EINVAL, "run_program: unknown op kind %d", o->kind);

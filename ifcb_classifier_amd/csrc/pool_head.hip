@@ -820,6 +820,19 @@ extern "C" int ifcbk_softmax_xent(ifcbk_ctx* ctx, const float* logits, const int
     IFCBK_LAUNCH_CHECK(ctx, "softmax_xent");
     return 0;
 }
+namespace {
+__global__ void step_counters_kernel(int64_t* nbt, int n, float* loss_sum, const float* loss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nbt && i < n) nbt[i] += 1;
+    if (i == 0 && loss_sum) loss_sum[0] += loss[0];
+}
+}  // namespace
+extern "C" int ifcbk_step_counters(ifcbk_ctx* ctx, int64_t* nbt, int n, float* loss_sum, const float* loss, void* stream) {
+    if (n < 0 || (loss_sum && !loss)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "step_counters: bad arguments");
+    hipLaunchKernelGGL(step_counters_kernel, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, ST, nbt, n, loss_sum, loss);
+    IFCBK_LAUNCH_CHECK(ctx, "step_counters");
+    return 0;
+}
 extern "C" int ifcbk_softmax(ifcbk_ctx* ctx, const float* logits, int N, int NC, float* probs, void* stream) {
     if (N <= 0) return 0;
     hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(N, 64)), dim3(64), 0, ST, logits, N, NC, probs);

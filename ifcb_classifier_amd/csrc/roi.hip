@@ -198,7 +198,11 @@ __global__ __launch_bounds__(320) void roi_resize3_kernel(RoiArgs a) {
     const int y0 = (int)(blockIdx.x - (unsigned)img * nrb) * RPB;
     const bool live = (int)threadIdx.x < a.S;
     const int x = live ? (int)threadIdx.x : a.S - 1;
-    const int h = a.hs[img], w = a.ws[img];
+    const int h = a.hs[img] > 0 ? a.hs[img] : 1, w = a.ws[img] > 0 ? a.ws[img] : 1;
+    // this kernel is chosen from the caller's max_h / max_w (kmax == 3: no ROI larger than the output).  A table entry that
+    // breaks that promise (stale maxima) must not read unstaged LDS: columns are clamped to what the staging below holds --
+    // such a ROI comes out wrong (its coefficient table was sized for three taps), never out of bounds
+    const int wl = w < 320 ? w : 320;
     const uint8_t* src = a.pixels + a.offs[img];
     const int fl = a.flips ? a.flips[img] : 0;
     const bool vflip = fl & 1, hflip = fl & 2;
@@ -216,13 +220,18 @@ __global__ __launch_bounds__(320) void roi_resize3_kernel(RoiArgs a) {
             tvv[r][j] = tv[(2 + j) * TS + y];
             int row = ymin + (j < yn ? j : yn - 1);
             if (vflip) row = h - 1 - row;
-            if ((int)threadIdx.x < w) srow[r][j][threadIdx.x] = src[(size_t)row * w + threadIdx.x];
+            row = row < 0 ? 0 : (row >= h ? h - 1 : row);
+            // (strided: a ROI wider than the block -- maxima understated by the caller -- still stages every column it reads)
+            for (int xx = (int)threadIdx.x; xx < wl; xx += (int)blockDim.x) srow[r][j][xx] = src[(size_t)row * w + xx];
         }
     }
     const int xmin = th[0], xn = th[TS];
     const int t0 = th[2 * TS], t1 = th[3 * TS], t2 = th[4 * TS];
     int c0 = xmin, c1 = xmin + (xn > 1 ? 1 : 0), c2 = xmin + (xn > 2 ? 2 : xn - 1);
     if (hflip) { c0 = w - 1 - c0; c1 = w - 1 - c1; c2 = w - 1 - c2; }
+    c0 = c0 < 0 ? 0 : (c0 >= wl ? wl - 1 : c0);
+    c1 = c1 < 0 ? 0 : (c1 >= wl ? wl - 1 : c1);
+    c2 = c2 < 0 ? 0 : (c2 >= wl ? wl - 1 : c2);
     __syncthreads();
     if (!live) return;
 #pragma unroll

@@ -41,17 +41,86 @@ def segment_plan(op_offsets, padded_size, total, nseg=8, last_frac=1.0 / 24):
     return segs
 
 
-def run_overlapped(segments, run_segment, grad_flat, all_reduce):
+def run_overlapped(segments, run_segment, grad_flat, all_reduce, mark=None):
     """launch backward segment by segment; right after a segment is enqueued, start the asynchronous
     all-reduce (sum) of the bucket it completed, then wait for all of them.  ``all_reduce(tensor)`` returns a
-    work handle with ``.wait()`` (torch.distributed async_op=True) or None."""
+    work handle with ``.wait()`` (torch.distributed async_op=True) or None.  ``mark(name)``: called with
+    'before_wait' once every segment and exchange is enqueued and with 'after_wait' behind the last wait -- bench.py
+    records an event pair there: the time the compute stream is blocked on the exchange (its exposed part)."""
     works = []
     for seg in segments:
         run_segment(seg)
         lo, hi = seg[2], seg[3]
         if hi > lo:
             works.append(all_reduce(grad_flat[lo:hi]))
+    if mark is not None:
+        mark('before_wait')
     for w in works:
         if w is not None:
             w.wait()
+    if mark is not None:
+        mark('after_wait')
     return len(works)
+
+
+EXCHANGES = ('allreduce', 'rsag')
+
+
+class _Chain:
+    """work handle of an exchange made of several collectives (reduce-scatter -> all-gather [+ tail all-reduce])"""
+
+    def __init__(self, works, then=None):
+        self.works, self.then = list(works), then
+
+    def wait(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if self.then is not None:
+            nxt, self.then = self.then(), None
+            self.works = []
+            if nxt is not None:
+                nxt.wait()
+        return True
+
+
+def exchange_mode(mode=None):
+    import os
+    mode = (mode or os.environ.get('IFCBK_DP_EXCHANGE', 'allreduce')).lower()
+    if mode not in EXCHANGES:
+        raise ValueError('IFCBK_DP_EXCHANGE must be one of %s, got %r' % ('|'.join(EXCHANGES), mode))
+    return mode
+
+
+def make_exchange(dist, mode=None, group=None):
+    """-> (callable(bucket) -> work handle, mode): the gradient exchange of one bucket (sum over ranks, in place).
+
+    allreduce  one ``all_reduce`` per bucket (torch ProcessGroupNCCL = RCCL; ring-shaped by default: every byte crosses
+               ONE xGMI link at a time, 2 (w-1)/w * bytes per link)
+    rsag       ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the bucket, in place (rank r owns elements
+               [r*c, (r+1)*c) of it, c = len // world; the < world leftover elements go through a small all_reduce):
+               on the fully connected 8-GPU xGMI node each rank exchanges 1/world of the bucket with every peer at once
+               (all seven links busy instead of one).  Sum order per element differs from the ring's for
+               world > 2 (deterministic for a fixed world), identical at world 2.
+    Both are asynchronous on the backend's own stream (RCCL) and overlap the backward segments launched behind them;
+    on gloo (CPU tests) the two phases are chained at wait(): its worker threads do not order work items.
+    The reference reaches this exchange through Lightning's ddp (neuston_net.py:102)."""
+    mode = exchange_mode(mode)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if mode == 'allreduce' or world == 1:
+        return (lambda t: dist.all_reduce(t, group=group, async_op=True)), mode
+    ordered = dist.get_backend(group) != 'gloo'       # stream-ordered backends run a group's collectives in issue order
+
+    def rsag(t):
+        n = t.numel()
+        c = n // world
+        m = c * world
+        tail = (lambda: dist.all_reduce(t[m:], group=group, async_op=True)) if m < n else (lambda: None)
+        if c == 0:
+            return tail()
+        shard = t[rank * c:(rank + 1) * c]
+        rs = dist.reduce_scatter_tensor(shard, t[:m], group=group, async_op=True)
+        if ordered:
+            return _Chain([rs, dist.all_gather_into_tensor(t[:m], shard, group=group, async_op=True), tail()])
+        return _Chain([rs, tail()], then=lambda: dist.all_gather_into_tensor(t[:m], shard, group=group, async_op=True))
+    return rsag, mode

@@ -157,7 +157,7 @@ class Engine:
     """Device state of one model replica."""
 
     def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16', optimizer='adam',
-                 momentum=0.0, plan_only=False):
+                 momentum=0.0, plan_only=False, train_batch=None):
         # plan_only: build buffers on the host and the op tables only (no HIP context, nothing can run) -- the CPU tests
         # of the data-parallel bucket plan read the REAL backward list of a network this way
         self.plan_only = bool(plan_only)
@@ -189,6 +189,10 @@ class Engine:
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
         self.window_batch = max(1, ((1 << 31) - 1) // per_img)
         self.max_batch = int(max_batch)
+        # capacity of the TRAINING-side buffers (activation gradients, d(raw) scratch, pool arg-max, split-K workspace): a training
+        # step beyond the window is refused anyway, so they never need more than it; an inference-only engine (neuston_net RUN:
+        # train_batch=1) keeps to activations -- 'RUN --batch 2048' must not allocate gradients for 2048 images
+        self.train_batch = max(1, min(self.max_batch, self.window_batch if train_batch is None else int(train_batch)))
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         self.packed = False
@@ -419,6 +423,7 @@ class Engine:
     # ------------------------------------------------------------------ activations
     def _alloc_acts(self):
         net, dev, N = self.net, self.dev, self.max_batch
+        Nt = self.train_batch
         bf = self.tdtype
         self.act = {}
         self.grad = {}
@@ -446,13 +451,23 @@ class Engine:
             b = net.bufs[bid]
             if b.name.endswith(':raw'):
                 continue
-            self.grad[bid] = torch.zeros(N, b.H, b.W, b.C, dtype=bf, device=dev)
-        # program lanes (branch-parallel streams) of the training programs: 4, data-parallel jobs included.  Round 1 pinned DP jobs
-        # to 2 lanes after a 2-rank rehearsal ON ONE GPU stalled with 3-4 (1.3-6.5 s/step): two processes' 5 streams each on one
-        # device's hardware queues.  Round 3 measured the DP step itself on the real backend (scripts/dp_lanes.py: ProcessGroupNCCL,
-        # world 1, batch 256, bucketed async all-reduces on RCCL's stream beside the lanes): 2 / 3 / 4 lanes = 25.57 / 24.15 /
-        # 23.98 ms (fused step: 24.78 / 23.64 / 23.50) -- no stall with one process per GPU, which is how DP jobs run.
-        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '4'))))
+            self.grad[bid] = torch.zeros(Nt, b.H, b.W, b.C, dtype=bf, device=dev)
+        # program lanes (branch-parallel streams) of the training programs: 4 on a single GPU, 2 in a data-parallel job (world > 1)
+        # until a run with one process per GPU on >= 2 GPUs shows 4 is no slower THERE.  Round 1 saw 1.3-6.5 s per step with 3-4
+        # lanes on a 2-rank rehearsal (two processes' 5 streams each on ONE device's hardware queues); round 3 measured the DP step
+        # on ProcessGroupNCCL at world 1 (scripts/dp_lanes.py: 2 / 3 / 4 lanes = 25.57 / 24.15 / 23.98 ms, no stall) -- but a
+        # world-1 all-reduce launches no RCCL ring kernels, so that run cannot show the lanes competing with them for CUs and
+        # hardware queues (main + 4 lanes + RCCL = 6 streams on 4 queues).  No multi-GPU node was available to this build: the
+        # conservative count ships, IFCBK_LANES overrides it, bench.py prints the count in `config.program_lanes`.
+        dp_world = 1
+        try:
+            import torch.distributed as _d
+            if _d.is_available() and _d.is_initialized():
+                dp_world = _d.get_world_size()
+        except Exception:
+            dp_world = 1
+        self.dp_world = dp_world
+        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2' if dp_world > 1 else '4'))))
         self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (measured best)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
         # launch list (6.73 vs 6.85 ms); the train fwd+bwd graph is 4 % SLOWER (28.7 vs 27.6 ms per step: the graph's own
@@ -466,9 +481,9 @@ class Engine:
         max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
         # the next node's BN backward already fills the other)
-        self.draw = [torch.zeros(N * max_raw, dtype=bf, device=dev) for _ in range(self.NL * (2 if self.wgrad_side_lane else 1))]
+        self.draw = [torch.zeros(Nt * max_raw, dtype=bf, device=dev) for _ in range(self.NL * (2 if self.wgrad_side_lane else 1))]
         gmax = max([g.x.H * g.x.W * g.Ktot for g in self.groups] + [0])
-        self.draw_group = torch.zeros(max(1, N * gmax), dtype=bf, device=dev)
+        self.draw_group = torch.zeros(max(1, Nt * gmax), dtype=bf, device=dev)
         mb = max([self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._conv_desc(n, N))) * 2 * n.K for n in self.convs] +
                  [self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(self._group_desc(g, N))) * 2 * g.Ktot for g in self.groups] +
                  [self.ctx.lib.ifcbk_bn_stats_rows(N * n.x.H * n.x.W) * 2 * n.K for n in self.bnrs] + [16])
@@ -476,7 +491,7 @@ class Engine:
         self.argmax = {}
         for k, n in enumerate(net.nodes):
             if n.kind == 'max':
-                self.argmax[k] = torch.zeros(N, n.P, n.Q, n.x.C, dtype=torch.uint8, device=dev)
+                self.argmax[k] = torch.zeros(Nt, n.P, n.Q, n.x.C, dtype=torch.uint8, device=dev)
         self.heads = [n for n in net.nodes if n.kind == 'head']
         for h in self.heads:
             h.feat = torch.zeros(N, h.C, dtype=torch.float32, device=dev)
@@ -512,20 +527,20 @@ class Engine:
         # workspace: wgrad split-K slabs / bn_bwd partials
         ws = 1 << 20
         for n in self.convs:
-            d = self._conv_desc(n, N)
+            d = self._conv_desc(n, Nt)
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
-            M = N * n.P * n.Q
+            M = Nt * n.P * n.Q
             ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         for g in self.groups:
-            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, N))))
+            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, Nt))))
         for n in self.plains:
-            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._conv_desc(n, N))),
-                     self.ctx.lib.ifcbk_bias_relu_bwd_workspace(N * n.P * n.Q, n.K))
+            ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._conv_desc(n, Nt))),
+                     self.ctx.lib.ifcbk_bias_relu_bwd_workspace(Nt * n.P * n.Q, n.K))
         for n in self.bnrs:
-            M = N * n.x.H * n.x.W
+            M = Nt * n.x.H * n.x.W
             ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         if self.stem_u8 is not None:
-            ws = max(ws, self.ctx.lib.ifcbk_stem_u8_wgrad_workspace(C.byref(self._conv_desc(self.stem_u8, N))))
+            ws = max(ws, self.ctx.lib.ifcbk_stem_u8_wgrad_workspace(C.byref(self._conv_desc(self.stem_u8, Nt))))
         self.ctx.reserve(ws)
 
     @property
@@ -700,22 +715,24 @@ class Engine:
             for v in ((m.x, getattr(m, 'residual', None)) if m.kind == 'conv' else (m.x,)):
                 if v is not None:
                     readers.setdefault(v.buf.id, []).append(m)
-        fused_pool = {}       # conv node -> (pool node, its index);  and the set of fused pool nodes
-        if os.environ.get('IFCBK_FUSE_POOL', '1') != '0':
-            for kk, m in enumerate(net.nodes):
-                if (m.kind == 'max' and m.R == 3 and m.S == 3 and m.sh == 2 and m.sw == 2 and m.ph <= 1 and m.pw <= 1
-                        and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1):
-                    prod = [c for c in net.nodes if c.kind == 'conv' and c.y.buf.id == m.x.buf.id]
-                    if (len(prod) == 1 and prod[0].y.is_full and prod[0].relu and prod[0].residual is None
-                            and prod[0].group is None and bool(prod[0].aux) == bool(m.aux)):
-                        fused_pool[prod[0]] = (m, kk)
+        pool_cand = {}        # conv node -> (pool node, its index): the candidates, whatever the switches say
+        for kk, m in enumerate(net.nodes):
+            if (m.kind == 'max' and m.R == 3 and m.S == 3 and m.sh == 2 and m.sw == 2 and m.ph <= 1 and m.pw <= 1
+                    and m.x.is_full and len(readers.get(m.x.buf.id, ())) == 1):
+                prod = [c for c in net.nodes if c.kind == 'conv' and c.y.buf.id == m.x.buf.id]
+                if (len(prod) == 1 and prod[0].y.is_full and prod[0].relu and prod[0].residual is None
+                        and prod[0].group is None and bool(prod[0].aux) == bool(m.aux)):
+                    pool_cand[prod[0]] = (m, kk)
+        # IFCBK_FUSE_POOL: the TRAINING fusion (bn_apply_maxpool / bn_bwd_maxpool); IFCBK_FUSE_POOL_EVAL: the eval one below --
+        # two switches, two decisions
+        fused_pool = dict(pool_cand) if os.environ.get('IFCBK_FUSE_POOL', '1') != '0' else {}
         fused_pool_nodes = {v[0] for v in fused_pool.values()}
         self.fused_pool = fused_pool
         # eval twin: conv + folded BatchNorm + ReLU + that max pool in ONE kernel where the row-streaming conv serves the layer
         # (inception Conv2d_2b -> maxpool1): the 708 MB activation of a batch of 256 is neither written nor read back
         fused_pool_eval = {}
         if os.environ.get('IFCBK_FUSE_POOL_EVAL', '1') != '0' and not self.plan_only:
-            for cn, (pn, pk) in fused_pool.items():
+            for cn, (pn, pk) in pool_cand.items():
                 if (pn.ph == 0 and pn.pw == 0 and cn.y.buf.C == cn.K
                         and self.ctx.lib.ifcbk_conv2d_fwd_affine_maxpool_ok(C.byref(self._conv_desc(cn, N)))):
                     fused_pool_eval[cn] = pn
@@ -1275,9 +1292,12 @@ class Engine:
             opt.add(_lib.OP_ADAM, 'adam', p=(_vp(self.P), _vp(self.G), _vp(self.M), _vp(self.V)),
                     i=(self.nparam_padded, 1), f=(self.lr, self.betas[0], self.betas[1], self.eps, 0.0, 1.0))
         pl.adam = Program(opt)
-        # fused train step = fwd + loss + bwd + adam + pack
+        # the step's bookkeeping in the step's own op table: num_batches_tracked += 1 of every BatchNorm, loss_sum += loss
+        cnt = OpList()
+        cnt.add(_lib.OP_STEP_COUNTERS, 'step_counters', p=(_vp(self.nbt), _vp(self.loss_sum), _vp(self.loss)), i=(self.nbt.numel(),))
+        # fused train step = fwd + loss + bwd + adam + pack (+ counters)
         allops = OpList()
-        for prog_ops in (fwd_t, lossl, bwd, opt, pack):
+        for prog_ops in (fwd_t, lossl, bwd, opt, pack, cnt):
             allops.extend(prog_ops)
         pl.step = Program(allops)
         pl.step_adam_idx = pl.step.find(_lib.OP_SGD if self.optimizer == 'sgd' else _lib.OP_ADAM)[0]
@@ -1294,6 +1314,7 @@ class Engine:
         ap = OpList()
         ap.extend(opt)
         ap.extend(pack)
+        ap.extend(cnt)
         pl.adam_pack = Program(ap)
         pl.bwd_list = bwd
         pl.ddp_segs = None
@@ -1359,7 +1380,7 @@ class Engine:
         pl.ddp_segs = segs
         return segs
 
-    def train_step_ddp(self, N, world, all_reduce):
+    def train_step_ddp(self, N, world, all_reduce, mark=None):
         """data-parallel step: gradient all-reduce (sum) of each finished tail bucket is launched right after
         the backward segment that completes it and overlaps the remaining backward; Adam divides by world."""
         self._check_train_batch(N)
@@ -1368,12 +1389,10 @@ class Engine:
         self.make_dropout_mask(N)
         self.run(pl.fwd_loss)
         from .dp import run_overlapped
-        run_overlapped(self.ddp_segments(pl), lambda seg: self.run(seg[0]), self.G, all_reduce)
+        run_overlapped(self.ddp_segments(pl), lambda seg: self.run(seg[0]), self.G, all_reduce, mark)
         self.step_count += 1
         self._set_update(pl.adam_pack.arr[0], 1.0 / world)
-        self.run(pl.adam_pack)
-        self.nbt += 1
-        self.loss_sum += self.loss
+        self.run(pl.adam_pack)                    # (Adam, repack, and the step's counters: nbt += 1, loss_sum += loss)
         self.eval_stats_ready = False
         return pl
 
@@ -1487,6 +1506,9 @@ class Engine:
         self.dropout_calls += 1
 
     def _check_train_batch(self, N):
+        if N > self.train_batch and N <= self.window_batch:
+            raise RuntimeError('batch %d > %d: this engine was built for inference (train_batch=%d): its gradient buffers hold %d image(s)'
+                               % (N, self.train_batch, self.train_batch, self.train_batch))
         if N > self.window_batch:
             raise RuntimeError('batch %d > %d: the 2 GiB buffer-descriptor window holds %d images of this network per launch, and '
                                'BatchNorm batch statistics cannot be taken over chunks: use a smaller --batch per GPU (more GPUs)'
@@ -1515,6 +1537,7 @@ class Engine:
         return pl
 
     def backward(self, N):
+        self._check_train_batch(N)
         self.run(self.plan(N).bwd)
 
     def _set_update(self, op, grad_scale=1.0):
@@ -1553,7 +1576,6 @@ class Engine:
             self.run(pl.adam_pack)
         else:
             self.ctx.run_program(pl.step.arr, pl.step.n, self.stream(), op_ms)
-        self.nbt += 1
-        self.loss_sum += self.loss
+        # (nbt += 1 and loss_sum += loss are the step's last op: no framework kernel between load_rois and the end of a step)
         self.eval_stats_ready = False
         return pl

@@ -80,6 +80,8 @@ class Bin:
                     w, h, start = int(float(cols[cx + 2])), int(float(cols[cx + 3])), int(float(cols[cx + 4]))
                     if w * h == 0:
                         continue
+                    if w < 0 or h < 0 or start < 0:
+                        raise ValueError('%s.adc row %d: negative ROI size or offset (w=%d h=%d start=%d)' % (self.basepath, n, w, h, start))
                     tg.append(n); of.append(start); hs.append(h); ws.append(w)
             self._table = dict(targets=np.asarray(tg, dtype=np.int64), offs=np.asarray(of, dtype=np.int64),
                                hs=np.asarray(hs, dtype=np.int32), ws=np.asarray(ws, dtype=np.int32))

@@ -17,6 +17,7 @@ import torch.nn as nn
 from . import graph
 from .engine import Engine
 
+import os
 import pickle
 import types
 
@@ -208,8 +209,14 @@ def load_pretrained_weights(backbone, path):
     try:
         # a plain torchvision state_dict (the usual third-party download) needs no arbitrary unpickling
         sd = torch.load(path, map_location='cpu', weights_only=True)
-    except Exception:
-        sd = load_checkpoint_file(path)        # a Lightning-style checkpoint holding one: the permissive loader of f-2
+    except pickle.UnpicklingError as e:
+        # the safe loader refused a global: the file is a full checkpoint (Lightning-style .ptl / .ckpt holding a state_dict).
+        # Unpickling that runs whatever the file says, so it needs the caller's word that the file is trusted; I/O errors and
+        # everything else propagate unchanged
+        if os.environ.get('IFCBK_TRUST_WEIGHTS', '0') in ('', '0'):
+            raise RuntimeError('--weights %s is not a plain state_dict (%s); loading a full checkpoint unpickles arbitrary '
+                               'objects: set IFCBK_TRUST_WEIGHTS=1 if you trust this file' % (path, str(e).splitlines()[0])) from e
+        sd = load_checkpoint_file(path)        # the permissive loader of f-2
     if isinstance(sd, dict) and 'state_dict' in sd:
         sd = sd['state_dict']
     sd = {(k[len('model.'):] if k.startswith('model.') else k): v for k, v in sd.items()}
@@ -242,7 +249,7 @@ class NeustonModel(nn.Module):
     aggregation.  ``training_step`` / ``validation_step`` / ``test_step`` accept the reference's batch tuples.
     The fused fast path (``fit_batch``) runs forward+loss+backward+Adam as one HIP program."""
 
-    def __init__(self, hparams, device=0, max_batch=None):
+    def __init__(self, hparams, device=0, max_batch=None, train_batch=None):
         super().__init__()
         if isinstance(hparams, dict):
             hparams = argparse.Namespace(**hparams)
@@ -253,7 +260,7 @@ class NeustonModel(nn.Module):
         self.model = get_namebrand_model(hparams.MODEL, len(hparams.classes), hparams.pretrained, device, mb,
                                          getattr(hparams, 'precision', 'bf16') or 'bf16', optimizer=opt,
                                          lr=float(getattr(hparams, 'learning_rate', None) or 0.001),
-                                         momentum=float(getattr(hparams, 'momentum', None) or 0.0))
+                                         momentum=float(getattr(hparams, 'momentum', None) or 0.0), train_batch=train_batch)
         self.best_val_loss = np.inf
         self.best_epoch = 0
         self.agg_train_loss = 0.0
@@ -334,6 +341,9 @@ class NeustonModel(nn.Module):
     def upload_bin(self, blob, offs, hs, ws):
         """one upload per bin: the raw .roi bytes and the offset / size table of its ROIs"""
         eng = self.model.engine
+        if len(hs) and (int(hs.min()) < 1 or int(ws.min()) < 1 or int(offs.min()) < 0
+                        or int((offs.astype('int64') + hs.astype('int64') * ws).max()) > blob.size):
+            raise ValueError('upload_bin: the ROI table has empty / negative entries or points past the %d-byte blob' % blob.size)
         slot_stream = eng.prefetch_stream()
         with torch.cuda.stream(slot_stream):
             host = torch.from_numpy(blob).pin_memory()
@@ -500,11 +510,12 @@ class NeustonModel(nn.Module):
         return out
 
     @classmethod
-    def load_from_checkpoint(cls, path, device=0, max_batch=None):
-        """never triggers the pretrained download/--weights requirement: the state_dict in the file is the model"""
+    def load_from_checkpoint(cls, path, device=0, max_batch=None, inference=False):
+        """never triggers the pretrained download/--weights requirement: the state_dict in the file is the model.
+        inference=True (neuston_net RUN): activations for max_batch images, gradient-side buffers for one"""
         ckpt = load_checkpoint_file(path)
         hp = dict(ckpt['hyper_parameters'])
-        obj = cls(hp, device=device, max_batch=max_batch)
+        obj = cls(hp, device=device, max_batch=max_batch, train_batch=1 if inference else None)
         obj.load_state_dict(ckpt['state_dict'])
         st = (ckpt.get('optimizer_states') or [None])[0]
         if st and st.get('state'):

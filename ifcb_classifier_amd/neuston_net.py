@@ -106,7 +106,11 @@ class Trainer:
             cur = nxt
 
     def _allreduce(self, t):
-        return self.dist.all_reduce(t, async_op=True)
+        # the bucket exchange: one all_reduce, or reduce-scatter + all-gather (IFCBK_DP_EXCHANGE=allreduce|rsag, dp.make_exchange)
+        if getattr(self, '_exchange', None) is None:
+            from .dp import make_exchange
+            self._exchange, self.exchange_mode = make_exchange(self.dist)
+        return self._exchange(t)
 
     def fit(self, model, train_loader, val_loader):
         dev = model.model.engine.dev
@@ -350,7 +354,7 @@ def do_run(args):
         if len(args.filter) < 2:
             raise argparse.ArgumentTypeError('Must be at least one KEYWORD')
     classifier = NeustonModel.load_from_checkpoint(args.MODEL, device=int(os.environ.get('LOCAL_RANK', 0)),
-                                                   max_batch=args.batch_size)
+                                                   max_batch=args.batch_size, inference=True)
     seed_everything(classifier.hparams.seed)
     # (a RUN batch beyond the 2 GiB buffer-descriptor window needs nothing here: results are per image, and the library cuts the
     #  convolutions of such a batch into launches over image groups)

@@ -196,6 +196,10 @@ int ifcbk_dropout_mask(ifcbk_ctx*, uint8_t* mask, int64_t n, float p, uint64_t s
 int ifcbk_softmax_xent(ifcbk_ctx*, const float* logits, const int64_t* target, int N, int NC, float weight,
                        float* loss_out, int loss_accumulate, float* dlogits, void* stream);
 int ifcbk_softmax(ifcbk_ctx*, const float* logits, int N, int NC, float* probs, void* stream);
+/* the bookkeeping of one fused train step, in the step's own op table (no framework kernel between the first and the last
+ * launch of a step): num_batches_tracked[0..n) += 1 of every BatchNorm ([PL]/torch: nn.BatchNorm2d.forward in training) and
+ * loss_sum += loss (the reference's train_loss is the SUM of the batch losses, neuston_models.py:85).  Either part may be NULL. */
+int ifcbk_step_counters(ifcbk_ctx*, int64_t* num_batches_tracked, int n, float* loss_sum, const float* loss, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * replaces torch.optim.Adam(lr=1e-3) neuston_models.py:63-64 (one flat launch instead of 292 loops)  */
@@ -352,7 +356,8 @@ enum {
     IFCBK_OP_FLATTEN_CHW,    /* p: x, flat; i: N, HW, C, ldx | dtype << 32; flags bit 0 accumulate, bit 2 to_chw                 */
     IFCBK_OP_STEM_U8_FWD,    /* p: g, w_master, ab, y, bn_part (nullable), scale, shift (both NULL: raw + statistics); flags bit 2 relu */
     IFCBK_OP_STEM_U8_WGRAD,  /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
-    IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL  /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
+    IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL, /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
+    IFCBK_OP_STEP_COUNTERS   /* p: num_batches_tracked (i64, nullable), loss_sum (nullable), loss; i[0] = number of BatchNorms      */
 };
 typedef struct {
     int32_t kind;

@@ -200,3 +200,41 @@ def _worker_engine_plan(rank, world, port):
 def test_ddp_buckets_from_the_engines_own_backward_list_world2_gloo():
     port = _free_port()
     mp.spawn(_worker_engine_plan, args=(2, port), nprocs=2, join=True)
+
+
+def _worker_exchange(rank, world, port):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ifcb_classifier_amd.dp import make_exchange, run_overlapped
+    g = torch.Generator().manual_seed(100 + rank)
+    sizes = [4, 1, 7, 4096 + 3, 2, 100001]            # buckets with and without a leftover (len % world != 0), one shorter than world
+    total = sum(sizes)
+    base = torch.randn(total, generator=g)
+    res = {}
+    for mode in ('allreduce', 'rsag'):
+        ex, name = make_exchange(dist, mode)
+        assert name == mode
+        flat = base.clone()
+        segs, hi = [], total
+        for k, n in enumerate(sizes):
+            segs.append((k, k + 1, hi - n, hi))
+            hi -= n
+        marks = []
+        n = run_overlapped(segs, lambda seg: None, flat, ex, mark=marks.append)
+        assert n == len(sizes) and marks == ['before_wait', 'after_wait']
+        res[mode] = flat
+    # reduce-scatter + all-gather is the same sum as the all-reduce: bit-equal at world 2 (one addition per element)
+    assert torch.equal(res['allreduce'], res['rsag'])
+    both = [torch.zeros(total) for _ in range(world)]
+    dist.all_gather(both, base)
+    assert torch.equal(res['rsag'], both[0] + both[1])
+    with pytest.raises(ValueError):
+        make_exchange(dist, 'ring-of-fire')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rsag_exchange_equals_allreduce_world2_gloo():
+    """IFCBK_DP_EXCHANGE=rsag (reduce-scatter + all-gather per bucket) against all_reduce on the same buckets"""
+    port = _free_port()
+    mp.spawn(_worker_exchange, args=(2, port), nprocs=2, join=True)
