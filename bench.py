@@ -283,7 +283,7 @@ def layer_roofline(eng, pl, nsteps, hbm_tbps=6.29):
         eng.ctx.lib.ifcbk_op_cost(C.byref(op), C.byref(fl), C.byref(by))
         st = stages.setdefault(stage_of(pl.step.tags[j]), dict(ms=0.0, conv_ms=0.0, conv_gflop=0.0))
         st['ms'] += tot[j]
-        if fl.value > 0 and by.value > 0 and op.kind in (1, 2, 3, 20, 22, 25, 29, 31):
+        if fl.value > 0 and by.value > 0 and op.kind in (1, 2, 3, 20, 22, 25, 29, 31, 39):
             bound = min(MFMA_BF16_PEAK_TFLOPS * 1e12, fl.value / by.value * hbm_tbps * 1e12)
             conv_ms += tot[j]
             conv_bound_ms += 1e3 * fl.value / bound

@@ -26,14 +26,14 @@ BF16, F32 = 0, 1
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
  OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD, OP_CONV_DGRAD_BNSTAT_TAB,
  OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD, OP_CONV_FWD_AFFINE_MAXPOOL,
- OP_STEP_COUNTERS) = range(1, 39)
+ OP_STEP_COUNTERS, OP_CONV_WGRAD_GROUP) = range(1, 40)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
             24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd', 31: 'conv_dgrad',
-            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine', 38: 'step_counters'}
+            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine', 38: 'step_counters', 39: 'conv_wgrad'}
 
 
 class ConvDesc(C.Structure):
@@ -67,6 +67,10 @@ class BsChunk(C.Structure):
     _fields_ = [('raw', C.c_void_p), ('stat', C.c_void_p), ('raw_ld', C.c_int32), ('stat_ld', C.c_int32)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [('d', ConvDesc), ('x', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p)]
+
+
 class PackItem(C.Structure):
     _fields_ = [('w_master', C.c_void_p), ('w', C.c_void_p), ('wT', C.c_void_p), ('K', C.c_int32), ('RS', C.c_int32),
                 ('C', C.c_int32), ('Cw', C.c_int32), ('first_block', C.c_int64), ('wT_ld', C.c_int32), ('pad_', C.c_int32)]
@@ -98,6 +102,10 @@ _PROTOS = {
     'ifcbk_conv2d_wgrad_segments': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp]),
     'ifcbk_bn_finalize_ld': (_i, [_vp, C.POINTER(BnDesc), _vp, _i, _i] + [_vp] * 9),
     'ifcbk_conv2d_wgrad_workspace': (_sz, [C.POINTER(ConvDesc)]),
+    'ifcbk_conv2d_wgrad_group': (_i, [_vp, _i, C.POINTER(ConvDesc), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _vp]),
+    'ifcbk_conv2d_wgrad_group_workspace': (_sz, [_i, C.POINTER(ConvDesc)]),
+    'ifcbk_conv2d_wgrad_group_member_kh': (_i, [C.POINTER(ConvDesc)]),
+    'ifcbk_conv2d_wgrad_group_info': (_i, [_i, C.POINTER(ConvDesc), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'ifcbk_conv2d_fwd_mblocks': (_i, [C.POINTER(ConvDesc)]),
     'ifcbk_weight_pack': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'ifcbk_weight_pack_multi': (_i, [_vp, _vp, _i, C.c_int64, _i, _vp]),

@@ -23,6 +23,7 @@
 // its load part, so rows read in phase g may be re-filled from phase g+1 on (conv_big needs g+2: it waits behind the barrier).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ void wpp_wait_vmcnt() {
 // part: the matrix pipe leaves the wave's scalar / vector-memory issue ports idle half of the time, while the load part is what
 // bounds the ping-pong (conv_big.hip's measurements)
 template <int KH, int DM>
-__global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
+__device__ __forceinline__ void wpp_run(const WppArgs& a, const int lin) {
     constexpr int BMK = 32 * KH;                     // output channels per block
     constexpr int NSA = (BMK + 63) / 64;             // dy sub-tiles
     constexpr int NP = NSA + 4;                      // LDS-DMA pieces per wave and K-step
@@ -72,7 +73,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int grp = wave >> 2, wc = wave & 3;
-    const int lin = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int split = lin / a.tiles;
     const int tile = lin - split * a.tiles;
     const int ktile = tile / a.tilesJ, jtile = tile - ktile * a.tilesJ;
@@ -273,6 +273,83 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
     }
 }
 
+template <int KH, int DM>
+__global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
+    wpp_run<KH, DM>(a, (int)xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// ---- grouped launch: ONE grid over the weight gradients of up to WPP_MAXG layers (round 4).
+// A 17x17 layer's dW is 192 x 1344: six tiles.  Alone it needs 42 pixel splits to fill the chip -- 252 blocks of 27 K-steps that
+// each end in a 196 KB fp32 slab store (50 MB per launch written, then read back by wgrad_reduce: 1.68x the algorithmic bytes),
+// and the prologue + slab store of a block are a quarter of its life.  The six 7-tap layers of one Inception-C block finish their
+// d(raw) tensors one after the other, but nothing consumes a weight gradient before the optimizer: run them as ONE grid, 36 tiles
+// x 7 splits -- the same 252 blocks, each with six times the K-steps, and one sixth of the slab bytes and reduce work per layer.
+// Members may differ in everything but the tile template (KH); block -> member by the prefix table, then the single-layer body.
+constexpr int WPP_MAXG = 8;
+struct WppGroup {
+    WppArgs a[WPP_MAXG];
+    int blk0[WPP_MAXG + 1];
+    int n;
+};
+template <int KH>
+__global__ __launch_bounds__(512) void conv_wgrad_ppg(WppGroup g) {
+    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;
+#pragma unroll
+    for (int q = 1; q < WPP_MAXG; ++q)
+        if (q < g.n && bid >= g.blk0[q]) gi = q;
+    const WppArgs a = g.a[gi];
+    wpp_run<KH, 0>(a, bid - g.blk0[gi]);
+}
+
+// slabs of every member -> its dW, one launch (the per-element sums are those of wgrad_reduce4: same order, same bits)
+struct WppReduceGroup {
+    const float* slab[WPP_MAXG];
+    float* dw[WPP_MAXG];
+    int nsplit[WPP_MAXG], total4[WPP_MAXG], blk0[WPP_MAXG + 1];
+    int n, accumulate;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce4g(WppReduceGroup g) {
+    __shared__ float4 part[4][64];
+    int gi = 0;
+#pragma unroll
+    for (int q = 1; q < WPP_MAXG; ++q)
+        if (q < g.n && (int)blockIdx.x >= g.blk0[q]) gi = q;
+    const int nsplit = g.nsplit[gi], total4 = g.total4[gi];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int i = ((int)blockIdx.x - g.blk0[gi]) * 64 + o;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < total4) {
+        const float4* src = reinterpret_cast<const float4*>(g.slab[gi]) + i;
+        const int64_t stride = total4;
+        float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        int sp = sg;
+        for (; sp + 4 < nsplit; sp += 8) {
+            const float4 a = src[sp * stride], b = src[(sp + 4) * stride];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (sp < nsplit) {
+            const float4 a = src[sp * stride];
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+        s = float4{s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+    }
+    part[sg][o] = s;
+    __syncthreads();
+    if (sg == 0 && i < total4) {
+        const float4 p0 = part[0][o], p1 = part[1][o], p2 = part[2][o], p3 = part[3][o];
+        float4 r = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                    (p0.w + p1.w) + (p2.w + p3.w)};
+        float4* dst = reinterpret_cast<float4*>(g.dw[gi]) + i;
+        if (g.accumulate) {
+            const float4 d0 = *dst;
+            r.x += d0.x; r.y += d0.y; r.z += d0.z; r.w += d0.w;
+        }
+        *dst = r;
+    }
+}
+
 int wpp_mode() {
     const char* e = getenv("IFCBK_WGRAD_PP");
     return e ? atoi(e) : 1;
@@ -317,9 +394,7 @@ bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh_out, int* nsplit_out,
     return true;
 }
 
-int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
-                          int split_len, hipStream_t st) {
-    WppArgs a;
+static void wpp_fill(WppArgs& a, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int split_len) {
     const int es = 2;
     a.x = x; a.dy = dy; a.slab = slab;
     a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * es);
@@ -332,6 +407,12 @@ int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* 
     a.tilesJ = cdiv(a.RSC, 256);
     a.tiles = cdiv(d->K, 32 * kh) * a.tilesJ;
     a.fPQ = make_fastdiv(d->P * d->Q); a.fQ = make_fastdiv(d->Q);
+}
+
+int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
+                          int split_len, hipStream_t st) {
+    WppArgs a;
+    wpp_fill(a, d, x, dy, slab, kh, split_len);
     const dim3 grid((unsigned)(a.tiles * nsplit)), block(512);
     // (DM = 1 -- the pieces issued from inside the MFMA cluster -- was 5-10 % slower everywhere and is no longer instantiated)
     if (kh == 4) hipLaunchKernelGGL((conv_wgrad_pp<4, 0>), grid, block, 0, st, a);
@@ -339,5 +420,135 @@ int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* 
     else if (kh == 6) hipLaunchKernelGGL((conv_wgrad_pp<6, 0>), grid, block, 0, st, a);
     else IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_pp: kh=%d", kh);
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_pp");
+    return 0;
+}
+
+// ---------------------------------------------------------------- grouped weight gradients (C-ABI: include/ifcbk.h)
+namespace {
+struct GroupPlan { int kh, nsplit[WPP_MAXG], split_len[WPP_MAXG], tiles[WPP_MAXG], blocks; size_t slab_off[WPP_MAXG], ws; };
+
+// channel tile of a member (the single-layer rule of ifcbk_wgrad_pp_plan) or 0 when the wide-tile kernel cannot take the layer
+int group_member_kh(const ifcbk_conv_desc* d) {
+    if (d->dtype != IFCBK_BF16 || d->Cw != d->C) return 0;
+    const int RSC = d->R * d->S * d->C;
+    if (RSC % 4 || d->K % 8 || d->C % 8 || d->ldx % 8 || d->ldy % 8) return 0;
+    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31)) return 0;
+    int best = 0;
+    double bestc = 0;
+    for (int kh = 4; kh <= 6; ++kh) {
+        const double c = (double)cdiv(d->K, 32 * kh) * (32 * kh + 24);
+        if (!best || c < bestc - 1e-9 || (c < bestc + 1e-9 && kh > best)) { best = kh; bestc = c; }
+    }
+    if (const char* e = getenv("IFCBK_WGRAD_PP_KH")) { const int f = atoi(e); if (f >= 4 && f <= 6) best = f; }
+    if (wpp_mode() < 2) {
+        // padded work of the (32*kh) x 256 tiling over the true K x RSC matrix: a 96 x 576 gradient (35x35 3x3 layers) would
+        // multiply 1.8x its size; 128-channel tiles ran at 0.81x of conv_wgrad_rows as single launches (IFCBK_WGRAD_GROUP_MINKH)
+        const double waste = (double)cdiv(d->K, 32 * best) * 32 * best * cdiv(RSC, 256) * 256 / ((double)d->K * RSC);
+        int minkh = 5;
+        if (const char* e = getenv("IFCBK_WGRAD_GROUP_MINKH")) minkh = atoi(e);
+        if (waste > 1.3 || best < minkh) return 0;
+    }
+    return best;
+}
+
+// one grid for all members: the fewest K-steps per block L such that sum_i tiles_i * ceil(steps_i / L) fits the chip once
+bool group_plan(int n, const ifcbk_conv_desc* ds, GroupPlan* gp) {
+    if (n < 1 || n > WPP_MAXG) return false;
+    const int mode = wpp_mode();
+    if (mode <= 0) return false;
+    int kh = 0;
+    int64_t steps[WPP_MAXG];
+    for (int i = 0; i < n; ++i) {
+        const int k = group_member_kh(&ds[i]);
+        if (!k || (kh && k != kh)) return false;
+        kh = k;
+        gp->tiles[i] = cdiv(ds[i].K, 32 * kh) * cdiv(ds[i].R * ds[i].S * ds[i].C, 256);
+        steps[i] = ((int64_t)ds[i].N * ds[i].P * ds[i].Q + 63) / 64;
+    }
+    const int cus = ifcbk_num_cus();
+    int64_t lo = 1, hi = 1;
+    for (int i = 0; i < n; ++i) hi = steps[i] > hi ? steps[i] : hi;
+    auto blocks_at = [&](int64_t L) { int64_t b = 0; for (int i = 0; i < n; ++i) b += (int64_t)gp->tiles[i] * ((steps[i] + L - 1) / L); return b; };
+    if (blocks_at(hi) > cus && mode < 2) return false;          // more tiles than CUs even unsplit: the single launches serve it
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (blocks_at(mid) <= cus) hi = mid; else lo = mid + 1;
+    }
+    int64_t L = lo < 8 ? 8 : lo;                                 // (a split shorter than 8 K-steps is all prologue)
+    size_t off = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t ns = (steps[i] + L - 1) / L;
+        const int64_t len = ((steps[i] + ns - 1) / ns) * 64;
+        const int64_t M = (int64_t)ds[i].N * ds[i].P * ds[i].Q;
+        ns = (M + len - 1) / len;
+        gp->nsplit[i] = (int)ns;
+        gp->split_len[i] = (int)len;
+        gp->slab_off[i] = off;
+        off += (size_t)ns * ds[i].K * ds[i].R * ds[i].S * ds[i].C * sizeof(float);
+        off = (off + 255) & ~(size_t)255;
+        blocks += gp->tiles[i] * (int)ns;
+    }
+    gp->kh = kh; gp->ws = off; gp->blocks = blocks;
+    if (mode < 2) {
+        // worth one grid only when it fills most of the chip with splits long enough to amortise a block's prologue + slab store
+        if (blocks < (3 * cus) / 4) return false;
+        for (int i = 0; i < n; ++i)
+            if (steps[i] / gp->nsplit[i] < 20) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int ifcbk_conv2d_wgrad_group_member_kh(const ifcbk_conv_desc* d) { return d ? group_member_kh(d) : 0; }
+
+extern "C" size_t ifcbk_conv2d_wgrad_group_workspace(int n, const ifcbk_conv_desc* descs) {
+    GroupPlan gp;
+    if (!descs || !group_plan(n, descs, &gp)) return 0;
+    return gp.ws;
+}
+
+extern "C" int ifcbk_conv2d_wgrad_group_info(int n, const ifcbk_conv_desc* descs, int* kh, int* blocks, int* nsplit) {
+    GroupPlan gp;
+    if (!descs || !group_plan(n, descs, &gp)) return IFCBK_EUNSUPPORTED;
+    if (kh) *kh = gp.kh;
+    if (blocks) *blocks = gp.blocks;
+    if (nsplit) for (int i = 0; i < n; ++i) nsplit[i] = gp.nsplit[i];
+    return IFCBK_OK;
+}
+
+extern "C" int ifcbk_conv2d_wgrad_group(ifcbk_ctx* ctx, int n, const ifcbk_conv_desc* descs, const void* const* xs, const void* const* dys,
+                                        float* const* dws, int accumulate, void* stream) {
+    if (!ctx || !descs || !xs || !dys || !dws) return IFCBK_EINVAL;
+    GroupPlan gp;
+    if (!group_plan(n, descs, &gp))
+        IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "wgrad_group: %d members are not one wide-tile group (bf16, C == Cw, one channel tile)", n);
+    if (gp.ws > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "wgrad_group: workspace %zu > reserved %zu (call ifcbk_ctx_reserve)", gp.ws, ctx->ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    WppGroup g;
+    WppReduceGroup r;
+    memset(&g, 0, sizeof(g));
+    memset(&r, 0, sizeof(r));
+    int blk = 0, rblk = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((uintptr_t)dws[i] % 16) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_group: dW of member %d is not 16-byte aligned", i);
+        float* slab = (float*)((char*)ctx->ws + gp.slab_off[i]);
+        wpp_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh, gp.split_len[i]);
+        g.blk0[i] = blk;
+        blk += gp.tiles[i] * gp.nsplit[i];
+        r.slab[i] = slab; r.dw[i] = dws[i]; r.nsplit[i] = gp.nsplit[i];
+        r.total4[i] = (int)((int64_t)descs[i].K * descs[i].R * descs[i].S * descs[i].C / 4);
+        r.blk0[i] = rblk;
+        rblk += cdiv(r.total4[i], 64);
+    }
+    for (int i = n; i <= WPP_MAXG; ++i) { g.blk0[i] = blk; r.blk0[i] = rblk; }
+    g.n = n; r.n = n; r.accumulate = accumulate;
+    const dim3 grid((unsigned)blk), block(512);
+    if (gp.kh == 4) hipLaunchKernelGGL((conv_wgrad_ppg<4>), grid, block, 0, st, g);
+    else if (gp.kh == 5) hipLaunchKernelGGL((conv_wgrad_ppg<5>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((conv_wgrad_ppg<6>), grid, block, 0, st, g);
+    IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_ppg");
+    hipLaunchKernelGGL(wgrad_reduce4g, dim3((unsigned)rblk), dim3(256), 0, st, r);
+    IFCBK_LAUNCH_CHECK(ctx, "wgrad_reduce4g");
     return 0;
 }

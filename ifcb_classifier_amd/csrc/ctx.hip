@@ -211,6 +211,16 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
         case IFCBK_OP_FLATTEN_CHW:
             return ifcbk_flatten_chw(c, (int)o->i[0], (int)o->i[1], (int)o->i[2], (int)(o->i[3] >> 32), p[0], (int)(o->i[3] & 0xffffffff),
                                      p[1], (o->flags >> 2) & 1, acc, st);
+        case IFCBK_OP_CONV_WGRAD_GROUP: {
+            const ifcbk_wgrad_item* it = (const ifcbk_wgrad_item*)p[0];
+            const int n = (int)o->i[0];
+            if (!it || n < 1 || n > 8) IFCBK_FAIL(c, IFCBK_EINVAL, "run_program: wgrad group of %d", n);
+            ifcbk_conv_desc ds[8];
+            const void *xs[8], *dys[8];
+            float* dws[8];
+            for (int k = 0; k < n; ++k) { ds[k] = it[k].d; xs[k] = it[k].x; dys[k] = it[k].dy; dws[k] = it[k].dw; }
+            return ifcbk_conv2d_wgrad_group(c, n, ds, xs, dys, dws, acc, st);
+        }
         case IFCBK_OP_STEP_COUNTERS:
             return ifcbk_step_counters(c, (int64_t*)p[0], (int)o->i[0], (float*)p[1], (const float*)p[2], st);
         case IFCBK_OP_DROPOUT_MASK:
@@ -234,8 +244,20 @@ static int lane_resources(ifcbk_ctx* c, int used) {
         for (int i = c->n_xev; i < 64; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
         c->n_xev = 64;
     }
+    // IFCBK_LANE_LOW_PRIO=<lane>: that lane's stream gets the LEAST stream priority (the engine's weight-gradient lane: its
+    // kernels are off the critical path and should yield CUs to the input-gradient chain)
+    static int low = -2;
+    if (low == -2) { const char* e = getenv("IFCBK_LANE_LOW_PRIO"); low = e ? atoi(e) : -1; }
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
-        if ((used >> l & 1) && !c->lane_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
+        if ((used >> l & 1) && !c->lane_st[l]) {
+            if (l == low) {
+                int least = 0, greatest = 0;
+                IFCBK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                IFCBK_HIP(c, hipStreamCreateWithPriority(&c->lane_st[l], hipStreamNonBlocking, least));
+            } else {
+                IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
+            }
+        }
     return IFCBK_OK;
 }
 
@@ -503,6 +525,17 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
             break;
         }
+        case IFCBK_OP_CONV_WGRAD_GROUP: {
+            const ifcbk_wgrad_item* it = (const ifcbk_wgrad_item*)o->p[0];
+            const int n = (int)o->i[0];
+            ifcbk_conv_desc ds[8];
+            int kh = 0;
+            if (it && n >= 1 && n <= 8) {
+                for (int k = 0; k < n; ++k) ds[k] = it[k].d;
+                if (ifcbk_conv2d_wgrad_group_info(n, ds, &kh, nullptr, nullptr) == IFCBK_OK) snprintf(name, cap, "conv_wgrad_ppg<%d>", kh);
+            }
+            break;
+        }
         case IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL: snprintf(name, cap, "conv_rows3x3<%d, %d, true>", o->u.conv.C, o->u.conv.K); break;
         case IFCBK_OP_STEM_U8_FWD: snprintf(name, cap, "stem_u8_fwd_kernel"); break;
         case IFCBK_OP_STEM_U8_WGRAD: snprintf(name, cap, "stem_u8_wgrad_kernel"); break;
@@ -540,6 +573,15 @@ extern "C" int ifcbk_op_cost(const ifcbk_op* o, double* flops, double* bytes) {
             double xin = (double)d.N * d.H * d.W * d.C * 2, yout = (double)d.N * d.P * d.Q * d.K * 2,
                    wb = (double)d.K * d.R * d.S * d.C * 2;
             by = xin + yout + wb + ((o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT || o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) ? xin : 0);      // + one read of the producer's raw output
+            break;
+        }
+        case IFCBK_OP_CONV_WGRAD_GROUP: {
+            const ifcbk_wgrad_item* it = (const ifcbk_wgrad_item*)o->p[0];
+            for (int k = 0; it && k < (int)o->i[0] && k < 8; ++k) {
+                const ifcbk_conv_desc& d = it[k].d;
+                fl += 2.0 * d.N * d.P * d.Q * d.K * d.R * d.S * d.Cw;
+                by += (double)d.N * d.H * d.W * d.C * 2 + (double)d.N * d.P * d.Q * d.K * 2 + (double)d.K * d.R * d.S * d.C * 2;
+            }
             break;
         }
         case IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL: {

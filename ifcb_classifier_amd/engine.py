@@ -16,13 +16,17 @@ from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
 # environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
-_DISPATCH_SWITCHES = ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+_DISPATCH_SWITCHES = ('IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
                       'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
                       'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
 
 
 def _dispatch_env():
     return tuple(os.environ.get(k) for k in _DISPATCH_SWITCHES)
+
+
+def dtype_is_bf16(eng):
+    return eng.dtype == 'bf16'
 
 
 def _vp(t, byte_off=0):
@@ -477,6 +481,12 @@ class Engine:
         self.graph_eval = gm not in ('0', 'off', 'none')
         self.graph_train = gm in ('1', 'all', 'train')
         self.wgrad_side_lane = os.environ.get('IFCBK_WGRAD_SIDE', '0') != '0' and self.NL > 1
+        # IFCBK_WGRAD_LANE=1 (round 4): EVERY weight gradient on the last lane, the branch chains on the others, and every layer keeps
+        # its d(raw) in a buffer of its own (4.6 GB at batch 256) -- the backward critical path is then BN-backward -> input gradient
+        # -> BN-backward ..., and the MFMA-bound weight gradients (6.7 ms of a step when each runs alone) fill in beside the
+        # HBM-bound BatchNorm / pool kernels instead of standing in front of every input gradient on its lane
+        self.wgrad_lane = (os.environ.get('IFCBK_WGRAD_LANE', '0') != '0' and self.NL >= 3 and not self.wgrad_side_lane
+                           and dtype_is_bf16(self))
         self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
         max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
@@ -810,8 +820,24 @@ class Engine:
 
         # training and eval programs get their own lane counts: measured (B=256) 2 / 3 / 4 lanes = 25.9 / 25.5 / 25.3 ms per
         # train step but 6.12 / 6.63 / 6.78 ms per eval forward (its kernels are few and wide: more lanes only add waits)
-        lane_of = assign_lanes(NL)
+        WL = NL - 1 if self.wgrad_lane else None          # the weight-gradient lane
+        lane_of = assign_lanes(NL - 1 if self.wgrad_lane else NL)
         lane_eval = assign_lanes(self.NL_eval)
+        if not hasattr(self, 'draw_own'):
+            self.draw_own = {}
+
+        def own_draw(m):
+            if m not in self.draw_own:
+                self.draw_own[m] = torch.zeros(self.train_batch * m.P * m.Q * m.K, dtype=self.tdtype, device=self.dev)
+            return self.draw_own[m]
+
+        def group_draw(gq):
+            """the merged d(raw) tensor of a sibling GEMM: the shared scratch, or the group's own when weight gradients have a lane"""
+            if not self.wgrad_lane:
+                return self.draw_group
+            if getattr(gq, 'draw_own', None) is None:
+                gq.draw_own = torch.zeros(self.train_batch * gq.x.H * gq.x.W * gq.Ktot, dtype=self.tdtype, device=self.dev)
+            return gq.draw_own
 
         # ---- resources for the lane scheduler: channel ranges of tensors
         def ra(v):
@@ -1087,6 +1113,48 @@ class Engine:
                                 None, None, self._stat(n, 4), self._stat(n, 5)), i=(0,), bn=bnd)
                 bwd_groups.append(('bnr', n, bnd))
 
+        # ---- grouped weight gradients (round 4): the wide-tile wgrads of one block that share a channel tile run as ONE split-K
+        # grid (ifcbk_conv2d_wgrad_group) behind the block's LAST such layer -- 1/n of the slab traffic and reduce work per layer,
+        # n times the K-steps per block.  Each member keeps its d(raw) in a buffer of its own until the group has run (the per-lane
+        # scratch is reused by the next layer's BatchNorm backward).  IFCBK_WGRAD_GROUP=0 switches it off.
+        wg_of, wg_groups = {}, []
+        if os.environ.get('IFCBK_WGRAD_GROUP', '1') != '0' and self.dtype == 'bf16' and not self.wgrad_side_lane:
+            buckets = {}
+            for gsp in reversed(bwd_groups):
+                if gsp[0] != 'conv':
+                    continue
+                n = gsp[1]
+                if n.group is not None or n.aux or (self.stem_u8 is n and self.in_kind[self.in_slot] == 'u8'):
+                    continue
+                dbw = ConvDesc.from_buffer_copy(gsp[2])
+                dbw.ldy = n.K
+                khv = self.ctx.lib.ifcbk_conv2d_wgrad_group_member_kh(C.byref(dbw))
+                if khv <= 0:
+                    continue
+                key = n.name.split('.')[0] if net.name == 'inception_v3' else n.name.rsplit('.', 1)[0]
+                buckets.setdefault((key, khv), []).append((n, dbw))
+            for (key, khv), mem in buckets.items():
+                for c0 in range(0, len(mem), 6):
+                    part = mem[c0:c0 + 6]
+                    if len(part) < 2:
+                        continue
+                    descs = (ConvDesc * len(part))(*[m[1] for m in part])
+                    need = self.ctx.lib.ifcbk_conv2d_wgrad_group_workspace(len(part), descs)
+                    if need == 0:
+                        continue                      # the library keeps such layers on their single launches
+                    grp_obj = dict(members=[m[0] for m in part], descs=[m[1] for m in part], ws=need, kh=khv, key=key)
+                    wg_groups.append(grp_obj)
+                    for m in part:
+                        wg_of[m[0]] = grp_obj
+            if wg_groups:
+                need = max(gq['ws'] for gq in wg_groups)
+                if not self.plan_only and need > self.ctx.lib.ifcbk_ctx_workspace_bytes(self.ctx.h):
+                    self.ctx.reserve(need)
+                for gq in wg_groups:
+                    for m in gq['members']:
+                        own_draw(m)
+        self.wgrad_groups = wg_groups
+
         # backward in reverse node order, resolving first-writer / accumulate flags
         for g in reversed(bwd_groups):
             if g[0] == 'head':
@@ -1159,6 +1227,13 @@ class Engine:
                             lane=lane_of[n], reads=[rg(n.y)], writes=[rg(n.x)])
             else:
                 _, n, d, bnd, draw, wT, needs_dgrad, di = g
+                wgq = wg_of.get(n)
+                own = wgq is not None or (self.wgrad_lane and (n.group is None or n.cpool is not None))
+                if own:
+                    draw = _vp(own_draw(n))               # kept until the (grouped / side-lane) weight gradient has read it
+                elif self.wgrad_lane:
+                    draw = _vp(group_draw(n.group), self.esize * n.koff)
+                LW = WL if self.wgrad_lane else None      # lane of this node's weight gradient (None: the node's own lane)
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 dres, lddres, dres_acc = None, 0, 0
                 if n.residual is not None:
@@ -1169,6 +1244,8 @@ class Engine:
                 L = lane_of[n]
                 cp = n.cpool is not None
                 rdraw = [rdg(n)] if (grp is not None and not cp) else [('draw', di, 0, 1)]     # d(raw): merged-group slice or the lane's scratch
+                if own:
+                    rdraw = [('drawn', id(n), 0, 1)]
                 rawp, _ld = self._raw_ptr(n)
                 if n in fused_pool:
                     pn, pk = fused_pool[n]
@@ -1200,18 +1277,19 @@ class Engine:
                     pn = n.cpool
                     ppd = PoolDesc(N, pn.x.H, pn.x.W, n.K, grp.Ktot, 3, 3, 1, 1, 1, 1, pn.P, pn.Q, n.K, self.cdtype)
                     bwd.add(_lib.OP_AVGPOOL_BWD, pn.name + '(' + n.name + ')',
-                            p=(draw, _vp(self.draw_group, self.esize * n.koff)), flags=0, pool=ppd, lane=L,
+                            p=(draw, _vp(group_draw(grp), self.esize * n.koff)), flags=0, pool=ppd, lane=L,
                             reads=rdraw, writes=[rdg(n)])
                 if grp is not None:
                     # fused siblings: every member's d(raw) lands in its slice of the merged scratch; the member that
                     # comes FIRST in forward order is the last one here and launches the single wgrad + dgrad
                     if grp.members[0] is n:
                         gd = self._group_desc(grp, N)
-                        gp = [_vp(self.draw_group)] + [self._pptr(m.conv_key + '.weight', 'G') for m in grp.members]
+                        gdraw = group_draw(grp)
+                        gp = [_vp(gdraw)] + [self._pptr(m.conv_key + '.weight', 'G') for m in grp.members]
                         gres = ('dg', id(grp), 0, grp.Ktot)
                         bwd.add(_lib.OP_CONV_WGRAD_SEG, '+'.join(m.name for m in grp.members),
                                 p=[self._aptr(grp.x), gp[0]] + gp[1:], i=[m.K for m in grp.members], conv=gd,
-                                lane=0, reads=[ra(grp.x), gres], writes=[])
+                                lane=0 if LW is None else LW, reads=[ra(grp.x), gres], writes=[])
                         acc = acc_flag(grp.x.buf)
                         tab = self._bs_table(grp, gd, readers, fused_pool) if (acc == 0 and fuse_level >= 2) else None
                         if tab is not None:
@@ -1222,27 +1300,42 @@ class Engine:
                             keep.extend([table, part])
                             rpt = ('bpt', id(grp), 0, 1)
                             bwd.add(_lib.OP_CONV_DGRAD_BNSTAT_TAB, '+'.join(m.name for m in grp.members),
-                                    p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True), _vp(table),
+                                    p=(_vp(gdraw), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True), _vp(table),
                                        _vp(part)), conv=gd, lane=0,
                                     reads=[gres] + [rraw(m) for m in prods] + [rst(m) for m in prods], writes=[rg(grp.x), rpt])
                             for m in prods:
                                 bnstat_done[m] = (_vp(part, 4 * m.y.coff), nrow, rpt, grp.x.C)
                         else:
                             bwd.add(_lib.OP_CONV_DGRAD, '+'.join(m.name for m in grp.members),
-                                    p=(_vp(self.draw_group), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
+                                    p=(_vp(gdraw), _vp(self.Wsh, self.esize * grp.wT_off), self._aptr(grp.x, True)),
                                     flags=acc, conv=gd, lane=0, reads=[gres], writes=[rg(grp.x)])
                     continue
                 dbw = ConvDesc.from_buffer_copy(d)
                 dbw.ldy = n.K                       # dy of the conv = the dense d(raw) scratch
                 # wgrad and dgrad only share their input d(raw); IFCBK_WGRAD_SIDE=1 puts the weight gradient on the neighbouring
                 # lane -- measured slower (31.5 vs 29.1 ms/step): the next node's bn_bwd must wait for it to release the scratch
-                if self.stem_u8 is n and self.in_kind[self.in_slot] == 'u8':
+                if wgq is not None:
+                    wgq.setdefault('seen', []).append(n)
+                    if len(wgq['seen']) == len(wgq['members']):
+                        # the block's last member in backward order: every member's d(raw) exists now
+                        mem = wgq['members']
+                        items = (_lib.WgradItem * len(mem))()
+                        for kq, (m, dq) in enumerate(zip(mem, wgq['descs'])):
+                            items[kq].d = dq
+                            items[kq].x = self._aptr(m.x).value
+                            items[kq].dy = self.draw_own[m].data_ptr()
+                            items[kq].dw = self._pptr(m.conv_key + '.weight', 'G').value
+                        keep.append(items)
+                        bwd.add(_lib.OP_CONV_WGRAD_GROUP, '+'.join(m.name for m in mem),
+                                p=[C.addressof(items)] + [items[kq].dw for kq in range(len(mem))], i=(len(mem),), lane=L if LW is None else LW,
+                                reads=[ra(m.x) for m in mem] + [('drawn', id(m), 0, 1) for m in mem], writes=[])
+                elif self.stem_u8 is n and self.in_kind[self.in_slot] == 'u8':
                     bwd.add(_lib.OP_STEM_U8_WGRAD, n.name,
                             p=(_vp(self.in_u8[self.in_slot]), draw, _vp(self.in_ab[self.in_slot]), self._pptr(ckey, 'G')), conv=dbw,
-                            lane=L, reads=[ra(n.x)] + rdraw, writes=[])
+                            lane=L if LW is None else LW, reads=[ra(n.x)] + rdraw, writes=[])
                 else:
                     bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
-                            lane=(L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L,
+                            lane=LW if LW is not None else ((L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L),
                             reads=[ra(n.x)] + rdraw, writes=[])
                 if needs_dgrad:
                     assert n.x.is_full
@@ -1350,6 +1443,8 @@ class Engine:
             return [(o.p[2] - base) // 4]
         if o.kind == _lib.OP_STEM_U8_WGRAD:
             return [(o.p[3] - base) // 4]
+        if o.kind == _lib.OP_CONV_WGRAD_GROUP:
+            return [(o.p[1 + k] - base) // 4 for k in range(int(o.i[0]))]
         if o.kind == _lib.OP_CONV_WGRAD_SEG:
             return [(o.p[2 + k] - base) // 4 for k in range(4) if o.i[k] > 0]
         # (a vgg*_bn conv's bias rides with its BatchNorm's gradients: nothing writes it -- the batch mean absorbs the bias, its

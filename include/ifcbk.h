@@ -103,6 +103,21 @@ int ifcbk_conv2d_wgrad(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const 
 int ifcbk_conv2d_wgrad_segments(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* dy, int nseg,
                                 float* const* dws, const int32_t* kseg, int accumulate, void* stream);
 size_t ifcbk_conv2d_wgrad_workspace(const ifcbk_conv_desc*);
+/* the weight gradients of n <= 8 INDEPENDENT layers (each as ifcbk_conv2d_wgrad: its own x, dy, dw and descriptor) as ONE
+ * split-K grid + ONE fixed-order reduce: the layers of an Inception block finish their dy one after the other, but no weight
+ * gradient is consumed before the optimizer (autograd computes them at the same place: aten::convolution_backward under
+ * neuston_models.py:81-86) -- together they fill the chip with 1/n of the pixel splits, i.e. 1/n of the fp32 slab traffic and
+ * reduce work per layer and n times the K-steps per block.  All members must take the same wide-tile template
+ * (bf16, C == Cw, equal channel tile): ifcbk_conv2d_wgrad_group_workspace returns 0 when they do not (then call
+ * ifcbk_conv2d_wgrad per layer).  descs / xs / dys / dws are host arrays.  Bitwise reproducible.                          */
+int ifcbk_conv2d_wgrad_group(ifcbk_ctx*, int n, const ifcbk_conv_desc* descs, const void* const* xs, const void* const* dys,
+                             float* const* dws, int accumulate, void* stream);
+size_t ifcbk_conv2d_wgrad_group_workspace(int n, const ifcbk_conv_desc* descs);
+/* the plan of such a group: channel tile (kh * 32 output channels), blocks of the grid, pixel splits per member          */
+int ifcbk_conv2d_wgrad_group_info(int n, const ifcbk_conv_desc* descs, int* kh, int* blocks, int* nsplit);
+/* channel tile (4, 5, 6 = 128 / 160 / 192 output channels per block) a layer would take inside a group, 0 = not a candidate
+ * (dtype, padded channels, or a tiling that would multiply more than 1.3x the layer's true K x RSC)                        */
+int ifcbk_conv2d_wgrad_group_member_kh(const ifcbk_conv_desc*);
 int  ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc*);   /* rows of bn_part */
 /* master fp32 [K][R][S][Cw] -> bf16 shadow [K][R][S][C] (zero padded) and, if wT!=NULL, the flipped
  * transposed dgrad shadow [C][R][S][K].                                                             */
@@ -357,8 +372,16 @@ enum {
     IFCBK_OP_STEM_U8_FWD,    /* p: g, w_master, ab, y, bn_part (nullable), scale, shift (both NULL: raw + statistics); flags bit 2 relu */
     IFCBK_OP_STEM_U8_WGRAD,  /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
     IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL, /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
-    IFCBK_OP_STEP_COUNTERS   /* p: num_batches_tracked (i64, nullable), loss_sum (nullable), loss; i[0] = number of BatchNorms      */
+    IFCBK_OP_STEP_COUNTERS,  /* p: num_batches_tracked (i64, nullable), loss_sum (nullable), loss; i[0] = number of BatchNorms      */
+    IFCBK_OP_CONV_WGRAD_GROUP /* p[0]: HOST array of i[0] ifcbk_wgrad_item (kept alive by the caller); p[1..]: the members' dw again
+                               * (what the data-parallel bucket planner reads); flags bit 0 accumulate                            */
 };
+typedef struct {
+    ifcbk_conv_desc d;
+    const void* x;
+    const void* dy;
+    float* dw;
+} ifcbk_wgrad_item;
 typedef struct {
     int32_t kind;
     int32_t flags;           /* bit 0 accumulate, bit 1 param accumulate, bit 2 relu (per kind), bit 3 dx accumulate (BN_BWD);

@@ -267,6 +267,78 @@ def test_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
     assert _rel(dw.cpu(), 2 * rdw) < 1e-4
 
 
+# grouped weight gradients (ifcbk_conv2d_wgrad_group, round 4): members with DIFFERENT filter shapes, maps, strides, tails and slices in
+# one split-K grid + one reduce; every member against torch's autograd, bitwise repeatable, accumulate, and the plan's own numbers
+WGROUPS = [
+    (6, [((3, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3), 0, 0), ((3, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), 8, 16),
+         ((2, 96, 19, 19, 136, 3, 3, 2, 2, 0, 0), 8, 0)]),                                   # 1x7 + 7x1 + stride-2 3x3 with a K tail
+    (5, [((2, 160, 17, 17, 160, 1, 7, 1, 1, 0, 3), 0, 0), ((2, 160, 17, 17, 160, 7, 1, 1, 1, 3, 0), 0, 0)]),   # the c7 = 160 pair of Mixed_6c / 6d
+    (4, [((2, 768, 9, 9, 328, 1, 1, 1, 1, 0, 0), 0, 8), ((5, 40, 15, 13, 72, 3, 3, 1, 1, 1, 1), 0, 0),
+         ((4, 64, 23, 9, 120, 5, 5, 1, 1, 2, 2), 8, 0), ((1, 128, 8, 8, 128, 3, 1, 1, 1, 1, 0), 0, 0)]),   # four members, every kind of tail
+]
+
+
+@pytest.mark.parametrize('kh,members', WGROUPS)
+def test_grouped_weight_gradient_forced(ctx, forced, kh, members):
+    from ifcb_classifier_amd import _lib
+    forced(IFCBK_WGRAD_PP=2, IFCBK_WGRAD_PP_KH=kh)
+    n = len(members)
+    st = _lib.cur_stream()
+    descs = (_lib.ConvDesc * n)()
+    xs, dys, dws = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    keep, refs, outs = [], [], []
+    for i, (case, lx, ly) in enumerate(members):
+        N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+        x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 40 + i, lx, ly)
+        descs[i] = _desc(case, P, Q, LDX, LDY)
+        assert ctx.lib.ifcbk_conv2d_wgrad_group_member_kh(C.byref(descs[i])) == kh
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        F.conv2d(xr, wr, None, (sh, sw), (ph, pw)).backward(dy)
+        refs.append((wr.grad.permute(0, 2, 3, 1), N * P * Q))
+        xp, _ = _slice(xb, lx // 2, Cc)
+        dyp, _ = _slice(dyb, ly // 2, K)
+        dw = torch.full((K, R, S, Cc), float('nan'), device='cuda')
+        xs[i], dys[i], dws[i] = xp.value, dyp.value, dw.data_ptr()
+        keep += [xb, dyb]
+        outs.append(dw)
+    need = ctx.lib.ifcbk_conv2d_wgrad_group_workspace(n, descs)
+    assert need > 0
+    khq, blocks, ns = C.c_int(), C.c_int(), (C.c_int * n)()
+    assert ctx.lib.ifcbk_conv2d_wgrad_group_info(n, descs, C.byref(khq), C.byref(blocks), ns) == 0
+    assert khq.value == kh and blocks.value >= n and all(v >= 1 for v in ns)
+    ctx.reserve(need)
+    # the op-table form names the grouped kernel
+    items = (_lib.WgradItem * n)()
+    for i in range(n):
+        items[i].d, items[i].x, items[i].dy, items[i].dw = descs[i], xs[i], dys[i], dws[i]
+    op = _lib.Op()
+    op.kind, op.p[0], op.i[0] = _lib.OP_CONV_WGRAD_GROUP, C.addressof(items), n
+    buf = C.create_string_buffer(64)
+    ctx.lib.ifcbk_op_kernel(C.byref(op), buf, 64)
+    assert buf.value.decode() == 'conv_wgrad_ppg<%d>' % kh
+    ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 0, st)
+    torch.cuda.synchronize()
+    first = [o.clone() for o in outs]
+    for o, (rdw, M) in zip(outs, refs):
+        assert _rel(o.cpu(), rdw) < 1e-4
+        err = (o.cpu() - rdw).abs().max().item()
+        assert err <= 2e-5 * max(1.0, rdw.abs().max().item()) * M ** 0.5, err
+    for o in outs:
+        o.fill_(float('nan'))
+    ctx.run_program((_lib.Op * 1)(op), 1, st)                # the same launch through the program runner
+    torch.cuda.synchronize()
+    for o, f in zip(outs, first):
+        assert torch.equal(o, f)                             # fixed split plan, fixed reduction order
+    ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 1, st)      # accumulate
+    torch.cuda.synchronize()
+    for o, (rdw, M) in zip(outs, refs):
+        assert _rel(o.cpu(), 2 * rdw) < 1e-4
+    # a member with another channel tile does not join
+    bad = (_lib.ConvDesc * 2)(descs[0], _desc((2, 64, 9, 9, 64 if kh != 4 else 192, 3, 3, 1, 1, 1, 1), 9, 9, 64, 64 if kh != 4 else 192))
+    if ctx.lib.ifcbk_conv2d_wgrad_group_member_kh(C.byref(bad[1])) != kh:
+        assert ctx.lib.ifcbk_conv2d_wgrad_group_workspace(2, bad) == 0
+
+
 # conv_flat: N, C, H, W, K, R, S, ph, pw | ldx / ldy padding
 FLAT = [
     ((3, 96, 17, 13, 96, 3, 3, 1, 1), 16, 8),      # odd map, slices
