@@ -6,7 +6,7 @@
 #include <string>
 #include "../../include/ifcbk.h"
 
-constexpr int IFCBK_MAX_LANES = 4;
+constexpr int IFCBK_MAX_LANES = 8;
 struct ifcbk_ctx {
     int device;
     void* ws;            // workspace arena of the lane that is launching (split-K slabs, BN partials, resize tables)

@@ -230,13 +230,13 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
 }
 
 // ---------------------------------------------------------------- program runner with lanes
-// An op carries its lane (flags bits 8-9) and a wait mask (bits 12-15): "before this op, make my lane wait for
-// everything queued so far on those lanes".  Lane 0 is the caller's stream; lanes 1-3 are ctx-owned streams.  The host
+// An op carries its lane (flags bits 8-10) and a wait mask (bits 12-19): "before this op, make my lane wait for
+// everything queued so far on those lanes".  Lane 0 is the caller's stream; lanes 1-7 are ctx-owned streams.  The host
 // (engine.py) computes lanes and masks from the static data flow, so independent branches of the graph overlap --
 // the tail of one kernel (a 578-block grid on 512 resident slots runs a nearly empty second round) is filled by the
 // next branch's kernel.  Every lane joins lane 0 at the end of the program: to the caller it is one stream-ordered call.
-static inline int op_lane(const ifcbk_op* o) { return (o->flags >> 8) & 3; }
-static inline int op_wait(const ifcbk_op* o) { return (o->flags >> 12) & 15; }
+static inline int op_lane(const ifcbk_op* o) { return (o->flags >> 8) & 7; }
+static inline int op_wait(const ifcbk_op* o) { return (o->flags >> 12) & 255; }
 
 // streams and ordering events of the lanes in `used` (created outside of any stream capture)
 static int lane_resources(ifcbk_ctx* c, int used) {
@@ -246,11 +246,15 @@ static int lane_resources(ifcbk_ctx* c, int used) {
     }
     // IFCBK_LANE_LOW_PRIO=<lane>: that lane's stream gets the LEAST stream priority (the engine's weight-gradient lane: its
     // kernels are off the critical path and should yield CUs to the input-gradient chain)
-    static int low = -2;
-    if (low == -2) { const char* e = getenv("IFCBK_LANE_LOW_PRIO"); low = e ? atoi(e) : -1; }
+    static int low = -2;                 // bit mask of lanes
+    if (low == -2) {
+        low = 0;
+        if (const char* e = getenv("IFCBK_LANE_LOW_PRIO"))
+            for (; *e; ++e) if (*e >= '1' && *e <= '7') low |= 1 << (*e - '0');
+    }
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if ((used >> l & 1) && !c->lane_st[l]) {
-            if (l == low) {
+            if (low >> l & 1) {
                 int least = 0, greatest = 0;
                 IFCBK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
                 IFCBK_HIP(c, hipStreamCreateWithPriority(&c->lane_st[l], hipStreamNonBlocking, least));
@@ -279,7 +283,7 @@ static int lane_order(ifcbk_ctx* c, hipStream_t waiter, hipStream_t waited) {
 
 // ev: null, or 2n events (start, stop of every op, recorded on the op's own lane)
 static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, hipEvent_t* ev, unsigned char* rec = nullptr) {
-    hipStream_t st[IFCBK_MAX_LANES] = {s0, nullptr, nullptr, nullptr};
+    hipStream_t st[IFCBK_MAX_LANES] = {s0};
     int used = 1;
     for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
     if (int e = lane_resources(c, used)) return e;

@@ -90,7 +90,7 @@ def schedule_lanes(meta):
     """(lane, wait mask) per op from the static data flow: an op waits for the lanes that hold an unfinished producer of
     something it reads, or an unfinished reader / writer of something it writes.  A wait covers everything queued on the
     waited lane so far (and, transitively, whatever that lane had waited for), which is remembered to skip redundant waits."""
-    NL = 4
+    NL = 8
     count = [0] * NL                              # ops queued per lane
     synced = [[0] * NL for _ in range(NL)]        # synced[L][j]: lane L is ordered after the first synced[L][j] ops of lane j
     table = {}                                    # resource -> [writer (lane, pos) or None, readers [(lane, pos)]]
@@ -471,7 +471,7 @@ class Engine:
         except Exception:
             dp_world = 1
         self.dp_world = dp_world
-        self.NL = max(1, min(4, int(os.environ.get('IFCBK_LANES', '2' if dp_world > 1 else '4'))))
+        self.NL = max(1, min(8, int(os.environ.get('IFCBK_LANES', '2' if dp_world > 1 else '4'))))
         self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (measured best)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
         # launch list (6.73 vs 6.85 ms); the train fwd+bwd graph is 4 % SLOWER (28.7 vs 27.6 ms per step: the graph's own
@@ -485,8 +485,9 @@ class Engine:
         # its d(raw) in a buffer of its own (4.6 GB at batch 256) -- the backward critical path is then BN-backward -> input gradient
         # -> BN-backward ..., and the MFMA-bound weight gradients (6.7 ms of a step when each runs alone) fill in beside the
         # HBM-bound BatchNorm / pool kernels instead of standing in front of every input gradient on its lane
-        self.wgrad_lane = (os.environ.get('IFCBK_WGRAD_LANE', '0') != '0' and self.NL >= 3 and not self.wgrad_side_lane
-                           and dtype_is_bf16(self))
+        self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '0'))       # number of weight-gradient lanes (the last ones)
+        if self.NL - self.wgrad_lane < 2 or self.wgrad_side_lane or not dtype_is_bf16(self):
+            self.wgrad_lane = 0
         self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
         max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
@@ -820,8 +821,9 @@ class Engine:
 
         # training and eval programs get their own lane counts: measured (B=256) 2 / 3 / 4 lanes = 25.9 / 25.5 / 25.3 ms per
         # train step but 6.12 / 6.63 / 6.78 ms per eval forward (its kernels are few and wide: more lanes only add waits)
-        WL = NL - 1 if self.wgrad_lane else None          # the weight-gradient lane
-        lane_of = assign_lanes(NL - 1 if self.wgrad_lane else NL)
+        WLs = list(range(NL - self.wgrad_lane, NL))        # the weight-gradient lanes
+        wl_next = [0]
+        lane_of = assign_lanes(NL - self.wgrad_lane)
         lane_eval = assign_lanes(self.NL_eval)
         if not hasattr(self, 'draw_own'):
             self.draw_own = {}
@@ -1233,7 +1235,10 @@ class Engine:
                     draw = _vp(own_draw(n))               # kept until the (grouped / side-lane) weight gradient has read it
                 elif self.wgrad_lane:
                     draw = _vp(group_draw(n.group), self.esize * n.koff)
-                LW = WL if self.wgrad_lane else None      # lane of this node's weight gradient (None: the node's own lane)
+                LW = None                                 # lane of this node's weight gradient (None: the node's own lane)
+                if self.wgrad_lane:
+                    LW = WLs[wl_next[0] % len(WLs)]       # (round-robin over the weight-gradient lanes, per NODE)
+                    wl_next[0] += 1
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
                 dres, lddres, dres_acc = None, 0, 0
                 if n.residual is not None:

@@ -385,8 +385,8 @@ typedef struct {
 typedef struct {
     int32_t kind;
     int32_t flags;           /* bit 0 accumulate, bit 1 param accumulate, bit 2 relu (per kind), bit 3 dx accumulate (BN_BWD);
-                              * bits 8-9 LANE of this op (0 = the caller's stream, 1-3 = ctx-owned streams),
-                              * bits 12-15 WAIT mask: lanes whose queued work must finish before this op starts.
+                              * bits 8-10 LANE of this op (0 = the caller's stream, 1-7 = ctx-owned streams),
+                              * bits 12-19 WAIT mask: lanes whose queued work must finish before this op starts.
                               * All lanes start after the caller's prior work and join lane 0 at program end. */
     void*   p[12];           /* pointer operands in the order of the typed entry point               */
     int64_t i[4];            /* scalar ints (per kind)                                                */

@@ -33,7 +33,7 @@ def _loss(out, y):
     return F.cross_entropy(out, y)
 
 
-ARB = 2.0      # HIP-vs-fp64 distance allowed, in units of the fp32 oracle's own distance to the fp64 oracle
+ARB = 1.5      # HIP-vs-fp64 distance allowed, in units of the oracle's own distance to the fp64 oracle (measured: 1.03-1.28)
 
 
 def _trajectories(name, nc, B, S, dtype, optimizer, steps=3, seed=0, arbiter=False):
@@ -118,13 +118,19 @@ def _trajectories(name, nc, B, S, dtype, optimizer, steps=3, seed=0, arbiter=Fal
                     u64 = p64[kk] - p0[kk].double()
                     arb_h[kk], arb_o[kk] = rel(uh.double(), u64), rel(uo.double(), u64)
             ob = dict(ora.named_buffers())
-            brel = {kk: rel(b.detach().cpu().float(), ob[kk].float()) for kk, b in hip.named_buffers() if not kk.endswith('num_batches_tracked')}
+            hb = {kk: b.detach().cpu().float() for kk, b in hip.named_buffers() if not kk.endswith('num_batches_tracked')}
+            brel = {kk: rel(b, ob[kk].float()) for kk, b in hb.items()}
+            barb_h = barb_o = None
+            if o64 is not None:
+                b64 = dict(o64.named_buffers())
+                barb_h = max(rel(b.double(), b64[kk].double()) for kk, b in hb.items())
+                barb_o = max(rel(ob[kk].double(), b64[kk].double()) for kk in hb)
             nbt_ok = all(int(b.item()) == k + 1 for kk, b in hip.named_buffers() if kk.endswith('num_batches_tracked'))
             wk = max(per, key=per.get)
             out.append(dict(upd=per[wk], upd_key=wk, w=max(wrel.values()), buf=max(brel.values()), flip=max(flips.values()),
                             loss_h=loss_h, loss_o=float(lo.item()), per_tensor=per, nbt_ok=nbt_ok,
                             upd_median=sorted(per.values())[len(per) // 2],
-                            arb_h=arb_h, arb_o=arb_o))
+                            arb_h=arb_h, arb_o=arb_o, barb_h=barb_h, barb_o=barb_o))
         return out
     finally:
         O.set_storage('bf16')
@@ -141,53 +147,58 @@ def _report(tag, traj):
               'BN buffers worst %.3e | worst sign-flip fraction %.3e'
               % (tag, k + 1, t['loss_h'], t['loss_o'], t['upd'], t['upd_key'], t['upd_median'], t['w'], t['buf'], t['flip']))
         if t['arb_h']:
-            print('%s step %d: update distance to the fp64 oracle: HIP median %.3e worst %.3e | fp32 oracle median %.3e worst %.3e'
-                  % (tag, k + 1, _med(t['arb_h']), max(t['arb_h'].values()), _med(t['arb_o']), max(t['arb_o'].values())))
+            print('%s step %d: update distance to the fp64 oracle: HIP median %.3e worst %.3e | oracle median %.3e worst %.3e | '
+                  'BN buffers: HIP %.3e oracle %.3e'
+                  % (tag, k + 1, _med(t['arb_h']), max(t['arb_h'].values()), _med(t['arb_o']), max(t['arb_o'].values()),
+                     t['barb_h'], t['barb_o']))
 
 
 def _arbitrated(t):
     """HIP no farther from the fp64 trajectory than ARB x the fp32 reference arithmetic is (median and worst tensor)"""
-    return (_med(t['arb_h']) <= ARB * _med(t['arb_o']) + 1e-6 and max(t['arb_h'].values()) <= ARB * max(t['arb_o'].values()) + 1e-6)
+    return (_med(t['arb_h']) <= ARB * _med(t['arb_o']) + 1e-6 and max(t['arb_h'].values()) <= ARB * max(t['arb_o'].values()) + 1e-6
+            and t['barb_h'] <= ARB * t['barb_o'] + 1e-6)
 
 
-# fp32 parity mode: (update rel worst, update rel median, weight rel, buffer rel) after the LAST of three un-resynced steps
-FP32_SGD = {'inception_v3': (5e-1, 5e-1, 5e-1, 5e-1), 'resnet18': (5e-1, 5e-1, 5e-1, 5e-1)}
-FP32_ADAM = {'inception_v3': (5e-1, 5e-1, 5e-1, 5e-1), 'resnet18': (5e-1, 5e-1, 5e-1, 5e-1)}
+# fp32 parity mode, FIRST step (before the trajectories' own chaos compounds): update rel (worst tensor, median), weight rel, BN buffers
+# -- measured on MI355X: inception_v3 3.3e-2 / 2.3e-2 / 3.3e-2 / 2.6e-6 with the fp32 oracle ITSELF 2.8e-2 / 1.8e-2 away from
+# its fp64 twin; after that the fp32 and fp64 oracles drift apart by 0.55 (step 2) and 0.77 (step 3) of the update, and so does
+# everything else: from step 2 on only the arbitrated bound means anything
+STEP1 = {'inception_v3': (8e-2, 5e-2, 8e-2, 1e-4), 'resnet18': (8e-2, 5e-2, 8e-2, 1e-4)}
 CASES = [('inception_v3', 10, 16, 299), ('resnet18', 2, 16, 224)]
+
+
+def _check(name, traj, loss_tol):
+    uw, um, ww, bb = STEP1[name]
+    t = traj[0]
+    assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
+    for t in traj:
+        assert t['nbt_ok']
+        assert abs(t['loss_h'] - t['loss_o']) < loss_tol * abs(t['loss_o'])
+        assert _arbitrated(t)
 
 
 @pytest.mark.parametrize('name,nc,B,S', CASES)
 def test_fp32_trained_weights_sgd(name, nc, B, S):
     traj = _trajectories(name, nc, B, S, 'fp32', 'sgd', arbiter=True)
     _report('fp32 SGD(0.005, m=0.9) ' + name, traj)
-    uw, um, ww, bb = FP32_SGD[name]
-    for t in traj:
-        assert t['nbt_ok']
-        assert abs(t['loss_h'] - t['loss_o']) < 1e-3 * abs(t['loss_o'])
-        assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
-        assert _arbitrated(t)
+    _check(name, traj, 5e-3)
 
 
 @pytest.mark.parametrize('name,nc,B,S', CASES)
 def test_fp32_trained_weights_adam(name, nc, B, S):
     traj = _trajectories(name, nc, B, S, 'fp32', 'adam', arbiter=True)
     _report('fp32 Adam(1e-3) ' + name, traj)
-    uw, um, ww, bb = FP32_ADAM[name]
-    for t in traj:
-        assert t['nbt_ok']
-        assert abs(t['loss_h'] - t['loss_o']) < 1e-3 * abs(t['loss_o'])
-        assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
-        assert _arbitrated(t)
+    _check(name, traj, 5e-3)
 
 
 @pytest.mark.parametrize('name,nc,B,S', CASES)
 def test_bf16_trained_weights_twin(name, nc, B, S):
-    """the performance mode against the bf16-STORAGE oracle: same test, its own (measured, printed) tolerance -- never quoted as
-    the fp32 parity"""
+    """the performance mode against the bf16-STORAGE oracle, arbitrated by the same fp64 trajectory: the HIP bf16 path must be as
+    close to it as the oracle's own bf16-storage arithmetic is -- its own (measured, printed) numbers, never quoted as the fp32 parity"""
     for optimizer in ('sgd', 'adam'):
-        traj = _trajectories(name, nc, B, S, 'bf16', optimizer)
+        traj = _trajectories(name, nc, B, S, 'bf16', optimizer, arbiter=True)
         _report('bf16 %s %s' % (optimizer, name), traj)
         for t in traj:
             assert t['nbt_ok']
             assert abs(t['loss_h'] - t['loss_o']) < 0.1 * abs(t['loss_o'])
-            assert t['upd_median'] < 0.5 and t['w'] < 5e-2 and t['buf'] < 5e-2
+            assert _arbitrated(t)
