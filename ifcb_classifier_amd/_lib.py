@@ -92,6 +92,7 @@ _PROTOS = {
     'ifcbk_ctx_destroy': (_i, [_vp]),
     'ifcbk_ctx_reserve': (_i, [_vp, _sz]),
     'ifcbk_ctx_workspace_bytes': (_sz, [_vp]),
+    'ifcbk_ctx_lane_priority': (_i, [_vp, _i]),
     'ifcbk_last_error': (C.c_char_p, [_vp]),
     'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

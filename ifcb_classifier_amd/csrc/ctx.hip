@@ -109,6 +109,20 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
 
 extern "C" size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* c) { return c ? c->ws_bytes : 0; }
 
+extern "C" int ifcbk_ctx_lane_priority(ifcbk_ctx* c, int low_mask) {
+    if (!c || low_mask < 0 || (low_mask & 1) || low_mask >= (1 << IFCBK_MAX_LANES)) return IFCBK_EINVAL;      // lane 0 is the caller's stream
+    if (low_mask == c->lane_low) return IFCBK_OK;
+    IFCBK_HIP(c, hipSetDevice(c->device));
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+        if (c->lane_st[l] && (((low_mask ^ c->lane_low) >> l) & 1)) {      // the stream exists with the other priority: make it anew
+            IFCBK_HIP(c, hipStreamSynchronize(c->lane_st[l]));
+            IFCBK_HIP(c, hipStreamDestroy(c->lane_st[l]));
+            c->lane_st[l] = nullptr;
+        }
+    c->lane_low = low_mask;
+    return IFCBK_OK;
+}
+
 extern "C" const char* ifcbk_last_error(ifcbk_ctx* c) { return c ? c->err : g_create_err; }
 
 static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
@@ -244,14 +258,17 @@ static int lane_resources(ifcbk_ctx* c, int used) {
         for (int i = c->n_xev; i < 64; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
         c->n_xev = 64;
     }
-    // IFCBK_LANE_LOW_PRIO=<lane>: that lane's stream gets the LEAST stream priority (the engine's weight-gradient lane: its
-    // kernels are off the critical path and should yield CUs to the input-gradient chain)
-    static int low = -2;                 // bit mask of lanes
-    if (low == -2) {
-        low = 0;
-        if (const char* e = getenv("IFCBK_LANE_LOW_PRIO"))
-            for (; *e; ++e) if (*e >= '1' && *e <= '7') low |= 1 << (*e - '0');
+    // lanes of c->lane_low (ifcbk_ctx_lane_priority; IFCBK_LANE_LOW_PRIO=<digits> overrides, "0" = none) get the LEAST stream
+    // priority: the engine's weight-gradient lane -- its kernels are off the critical path and yield CUs to the input-gradient chain
+    static int envlow = -2;
+    if (envlow == -2) {
+        envlow = -1;
+        if (const char* e = getenv("IFCBK_LANE_LOW_PRIO")) {
+            envlow = 0;
+            for (; *e; ++e) if (*e >= '1' && *e <= '7') envlow |= 1 << (*e - '0');
+        }
     }
+    const int low = envlow >= 0 ? envlow : c->lane_low;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if ((used >> l & 1) && !c->lane_st[l]) {
             if (low >> l & 1) {

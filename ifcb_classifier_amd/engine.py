@@ -485,10 +485,17 @@ class Engine:
         # its d(raw) in a buffer of its own (4.6 GB at batch 256) -- the backward critical path is then BN-backward -> input gradient
         # -> BN-backward ..., and the MFMA-bound weight gradients (6.7 ms of a step when each runs alone) fill in beside the
         # HBM-bound BatchNorm / pool kernels instead of standing in front of every input gradient on its lane
-        self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '0'))       # number of weight-gradient lanes (the last ones)
-        if self.NL - self.wgrad_lane < 2 or self.wgrad_side_lane or not dtype_is_bf16(self):
+        # default: ONE weight-gradient lane (the last) when there are at least 3 lanes.  Measured at batch 256, same box, ms/step:
+        # 4 chain lanes 22.67 | 3 chains + 1 weight-gradient lane 21.72 | the same with that lane's stream at low priority 21.60 |
+        # 2 + 1 lanes 22.34 | FIVE streams (4 + 1, 3 + 2) 27.7, six 31.8: this runtime has four hardware queues per process.
+        self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '1' if self.NL >= 3 else '0'))       # number of weight-gradient lanes
+        if self.NL - self.wgrad_lane < 1 or self.wgrad_side_lane:
             self.wgrad_lane = 0
-        self.side_min_pix = int(os.environ.get('IFCBK_WGRAD_SIDE_MINPIX', '0'))
+        if not self.plan_only:
+            low = 0
+            for l in range(self.NL - self.wgrad_lane, self.NL):
+                low |= 1 << l
+            self.ctx.call('ifcbk_ctx_lane_priority', low & ~1)
         max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
         # the next node's BN backward already fills the other)

@@ -44,6 +44,9 @@ int  ifcbk_ctx_destroy(ifcbk_ctx* ctx);
 /* grow the ctx-owned workspace (split-K slabs, resize coefficient tables) to >= bytes; syncs the device */
 int  ifcbk_ctx_reserve(ifcbk_ctx* ctx, size_t bytes);
 size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* ctx);
+/* program lanes (see ifcbk_op.flags) whose ctx-owned streams get the LEAST stream priority; bit l = lane l, lane 0 (the caller's
+ * stream) cannot be named.  Call before the first program runs, or between programs (existing lane streams are re-created). */
+int  ifcbk_ctx_lane_priority(ifcbk_ctx* ctx, int low_mask);
 const char* ifcbk_last_error(ifcbk_ctx* ctx);
 
 /* ------------------------------------------------------------------ convolution (implicit GEMM, MFMA)

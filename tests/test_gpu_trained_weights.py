@@ -159,16 +159,21 @@ def _arbitrated(t):
             and t['barb_h'] <= ARB * t['barb_o'] + 1e-6)
 
 
-# fp32 parity mode, FIRST step (before the trajectories' own chaos compounds): update rel (worst tensor, median), weight rel, BN buffers
-# -- measured on MI355X: inception_v3 3.3e-2 / 2.3e-2 / 3.3e-2 / 2.6e-6 with the fp32 oracle ITSELF 2.8e-2 / 1.8e-2 away from
-# its fp64 twin; after that the fp32 and fp64 oracles drift apart by 0.55 (step 2) and 0.77 (step 3) of the update, and so does
-# everything else: from step 2 on only the arbitrated bound means anything
-STEP1 = {'inception_v3': (8e-2, 5e-2, 8e-2, 1e-4), 'resnet18': (8e-2, 5e-2, 8e-2, 1e-4)}
+# fp32 parity mode, FIRST step (before the trajectories' own chaos compounds): update rel (worst tensor, median), weight rel, BN
+# buffers.  Measured on MI355X at batch 16 (HIP vs fp32 oracle | the fp32 oracle ITSELF vs its fp64 twin):
+#   SGD  inception_v3  3.3e-2 / 2.3e-2 | 2.8e-2 / 1.8e-2       resnet18  7.4e-3 / 3.7e-3 | 1.1e-2 / 2.9e-3
+#   Adam inception_v3  4.3e-1 / 1.6e-1 | 3.5e-1 / 1.4e-1       resnet18  2.5e-1 / 9.3e-4 | 2.5e-1 / 1.2e-4
+# (Adam's first step is -lr * sign(g): a tensor whose gradient is at rounding-noise level flips whole elements.)  After step 1 the
+# fp32 and fp64 ORACLES drift apart by 0.55 and 0.77 of the update (inception, SGD steps 2 and 3), and so does everything else:
+# from step 2 on only the arbitrated bound means anything.  bf16 storage: both the HIP path and the bf16-storage oracle sit 1.3
+# (inception) / 0.4-0.7 (resnet18) of the update away from the fp64 trajectory from the FIRST step on -- equal to each other within 5 %.
+STEP1 = {('sgd', 'inception_v3'): (8e-2, 5e-2, 8e-2, 1e-4), ('sgd', 'resnet18'): (2e-2, 1e-2, 2e-2, 1e-5),
+         ('adam', 'inception_v3'): (0.9, 0.3, 0.9, 1e-4), ('adam', 'resnet18'): (0.6, 5e-3, 0.6, 1e-5)}
 CASES = [('inception_v3', 10, 16, 299), ('resnet18', 2, 16, 224)]
 
 
-def _check(name, traj, loss_tol):
-    uw, um, ww, bb = STEP1[name]
+def _check(opt, name, traj, loss_tol):
+    uw, um, ww, bb = STEP1[(opt, name)]
     t = traj[0]
     assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
     for t in traj:
@@ -181,14 +186,14 @@ def _check(name, traj, loss_tol):
 def test_fp32_trained_weights_sgd(name, nc, B, S):
     traj = _trajectories(name, nc, B, S, 'fp32', 'sgd', arbiter=True)
     _report('fp32 SGD(0.005, m=0.9) ' + name, traj)
-    _check(name, traj, 5e-3)
+    _check('sgd', name, traj, 5e-3)
 
 
 @pytest.mark.parametrize('name,nc,B,S', CASES)
 def test_fp32_trained_weights_adam(name, nc, B, S):
     traj = _trajectories(name, nc, B, S, 'fp32', 'adam', arbiter=True)
     _report('fp32 Adam(1e-3) ' + name, traj)
-    _check(name, traj, 5e-3)
+    _check('adam', name, traj, 4e-2)
 
 
 @pytest.mark.parametrize('name,nc,B,S', CASES)
