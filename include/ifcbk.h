@@ -376,7 +376,7 @@ enum {
     IFCBK_OP_STEM_U8_WGRAD,  /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
     IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL, /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
     IFCBK_OP_STEP_COUNTERS,  /* p: num_batches_tracked (i64, nullable), loss_sum (nullable), loss; i[0] = number of BatchNorms      */
-    IFCBK_OP_CONV_WGRAD_GROUP /* p[0]: HOST array of i[0] ifcbk_wgrad_item (kept alive by the caller); p[1..]: the members' dw again
+    IFCBK_OP_CONV_WGRAD_GROUP /* p[0]: HOST array of i[0] ifcbk_wgrad_item entries, kept alive by the caller; p[1..]: the members' dw again
                                * (what the data-parallel bucket planner reads); flags bit 0 accumulate                            */
 };
 typedef struct {
