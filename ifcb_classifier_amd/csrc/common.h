@@ -157,6 +157,10 @@ int ifcbk_conv_rows_pool_launch(ifcbk_ctx* ctx, int N, int H, int W, int ldx, in
 int ifcbk_num_cus();
 // conv_big.hip: wide-tile (256/320 pixels x 128..256 channels) ping-pong kernel; plan = does it serve this GEMM, and with which tile
 bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt, int* tn);
+// persistent wide-tile kernel (conv_pp3.hip): epi 0 = raw store (+ statistics), 1 = eval affine (+ReLU)
+bool ifcbk_conv_pp3_plan(int dtype, int M, int K, int Kg, int epi);
+int ifcbk_conv_pp3_launch(ifcbk_ctx* ctx, void* conv_args, hipStream_t st);
+void ifcbk_conv_pp3_name(int Kg, bool affine, bool plain, char* name, size_t cap);
 int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* conv_args, int mt, int tn, hipStream_t st);
 // conv_wgrad_pp.hip: wide-tile ping-pong weight gradient (plan: channel tile 32*kh, pixel splits)
 bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh, int* nsplit, int* split_len);

@@ -561,6 +561,9 @@ void launch_ws(const ConvArgs& a, hipStream_t st) {
 
 // the wide-tile kernel serves plain gathers (forward of any stride, stride-1 input gradients), with every epilogue variant
 bool big_ok(const ConvArgs& a) { return !a.wKg && !(a.ish | a.isw); }
+bool pp3_ok(const ConvArgs& a) {
+    return big_ok(a) && !a.seg_n && !a.bs_raw && !a.bs_tab && !a.accumulate && !a.ep_res && (a.ep_scale == nullptr || a.part == nullptr);
+}
 
 int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;
@@ -570,6 +573,8 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
         if (ifcbk_conv_flat_rows(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
             return ifcbk_conv_flat_launch(ctx, &a, N, st);
     }
+    // grids of several tiles per CU whose epilogue is a raw store (+ statistics) or the eval affine: the persistent kernel
+    if (pp3_ok(a) && ifcbk_conv_pp3_plan(dtype, a.M, a.K, a.Kg, a.ep_scale ? 1 : 0)) return ifcbk_conv_pp3_launch(ctx, &a, st);
     {
         int bmt = 0, btn = 0;
         if (big_ok(a) && ifcbk_conv_big_plan(dtype, a.M, a.K, a.Kg, &bmt, &btn)) return ifcbk_conv_big_launch(ctx, &a, bmt, btn, st);
@@ -638,6 +643,7 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     int M = d->N * d->P * d->Q;
     if (d->stride_h == 1 && d->stride_w == 1)
         if (int fs = ifcbk_conv_flat_rows(d->dtype, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->pad_h, d->pad_w, d->P, d->Q)) return fs;
+    if (ifcbk_conv_pp3_plan(d->dtype, M, d->K, d->R * d->S * d->C, 0)) return 2 * cdiv(M, 256);      // conv_pp3: one partial row per pixel half
     {
         int bmt = 0, btn = 0;
         if (ifcbk_conv_big_plan(d->dtype, M, d->K, d->R * d->S * d->C, &bmt, &btn)) return cdiv(M, 32 * bmt);

@@ -493,6 +493,12 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 snprintf(name, cap, "conv_flat<%d, %d, %d, %d, 0>", d.C, d.K, d.R, d.S);
                 break;
             }
+            if (!rows && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]) &&
+                ifcbk_conv_pp3_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, o->kind == IFCBK_OP_CONV_FWD_AFFINE ? 1 : 0)) {
+                ifcbk_conv_pp3_name(d.R * d.S * d.C, o->kind == IFCBK_OP_CONV_FWD_AFFINE,
+                                    d.R == 1 && d.S == 1 && d.pad_h == 0 && d.pad_w == 0 && d.stride_h == 1 && d.stride_w == 1, name, cap);
+                break;
+            }
             if (!rows && ifcbk_conv_big_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, &bmt, &btn)) {
                 snprintf(name, cap, "conv_pp2<%d, %d, %d, 0>", btn, bmt, bmt == 10 ? 4 : bmt / 2);
                 break;
@@ -520,6 +526,10 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                     break;
                 }
                 int bmt = 0, btn = 0;
+                if (!s2 && o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && ifcbk_conv_pp3_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, 0)) {
+                    ifcbk_conv_pp3_name(d.R * d.S * d.K, false, d.R == 1 && d.S == 1 && d.pad_h == 0 && d.pad_w == 0, name, cap);
+                    break;
+                }
                 if (!s2 && ifcbk_conv_big_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, &bmt, &btn)) {
                     snprintf(name, cap, "conv_pp2<%d, %d, %d, %d>", btn, bmt, bmt == 10 ? 4 : bmt / 2, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT_TAB ? 5 : 0);
                     break;

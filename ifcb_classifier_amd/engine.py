@@ -16,7 +16,7 @@ from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
 # environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
-_DISPATCH_SWITCHES = ('IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+_DISPATCH_SWITCHES = ('IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
                       'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
                       'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
 
@@ -488,7 +488,8 @@ class Engine:
         # default: ONE weight-gradient lane (the last) when there are at least 3 lanes.  Measured at batch 256, same box, ms/step:
         # 4 chain lanes 22.67 | 3 chains + 1 weight-gradient lane 21.72 | the same with that lane's stream at low priority 21.60 |
         # 2 + 1 lanes 22.34 | FIVE streams (4 + 1, 3 + 2) 27.7, six 31.8: this runtime has four hardware queues per process.
-        self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '1' if self.NL >= 3 else '0'))       # number of weight-gradient lanes
+        # Two lanes (the data-parallel default): 2 chains 22.90 | 1 chain + 1 weight-gradient lane 22.52.
+        self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '1' if self.NL >= 2 else '0'))       # number of weight-gradient lanes
         if self.NL - self.wgrad_lane < 1 or self.wgrad_side_lane:
             self.wgrad_lane = 0
         if not self.plan_only:

@@ -41,7 +41,7 @@ def _kname(ctx, d, kind, flags=0, residual=False):
 def forced(monkeypatch):
     def set_(**kw):
         for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
-                  'IFCBK_CONV_FLAT'):
+                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID'):
             monkeypatch.delenv(k, raising=False)
         for k, v in kw.items():
             monkeypatch.setenv(k, str(v))
@@ -92,7 +92,7 @@ WIDE = [
 @pytest.mark.parametrize('case,mt,tn,lx,ly', WIDE)
 def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, lx, ly):
     from ifcb_classifier_amd import _lib
-    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0)
+    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)
     if mt:
         env.update(IFCBK_CONV_BIG_MT=mt, IFCBK_CONV_BIG_TN=tn)
     forced(**env)
@@ -265,6 +265,94 @@ def test_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
     ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 1, st)      # accumulate
     torch.cuda.synchronize()
     assert _rel(dw.cpu(), 2 * rdw) < 1e-4
+
+
+# conv_pp3 (round 4): the PERSISTENT wide-tile kernel -- seamless tile switch, deferred register-direct stores, statistics by DPP row
+# sums, eval affine from LDS-staged coefficients.  grid: blocks of the launch (IFCBK_CONV_PP3_GRID test hook): with 2-3 blocks every
+# block walks several tiles, so the tile boundary (parity running on, gather switch, pack, deferred stores of tile i inside tile
+# i + 1) is what is tested; 0 = the launch's own grid (one tile per block on these sizes: only the exposed last-tile epilogue).
+PP3 = [
+    ((9, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3), 3, 0, 0),          # 11 tiles on 3 blocks, inception's 1x7, M tail (2601 pixels), SPP 1
+    ((6, 160, 17, 17, 200, 7, 1, 1, 1, 3, 0), 2, 16, 24),        # two N tiles (K tail 8 of 192), Kg tail, channel slices, SPP 1
+    ((4, 768, 17, 17, 384, 1, 1, 1, 1, 0, 0), 3, 0, 8),          # plain 1x1 GEMM (the sibling-GEMM shape), 5 M tiles x 2 N tiles, SPP 1
+    ((3, 96, 23, 19, 136, 3, 3, 2, 2, 0, 0), 2, 8, 0),           # stride-2 forward, 136 of 192 channels, SPP 1 (nk = 14)
+    ((5, 40, 15, 13, 72, 3, 3, 1, 1, 1, 1), 2, 0, 0),            # nk = 6: SPP 2
+    ((6, 256, 9, 9, 264, 1, 1, 1, 1, 0, 0), 0, 0, 0),            # nk = 4: SPP 3, the launch's own grid
+    ((2, 64, 40, 31, 192, 3, 3, 1, 1, 1, 1), 5, 0, 16),          # 10 tiles on 5 blocks: two tiles each
+]
+
+
+@pytest.mark.parametrize('case,grid,lx,ly', PP3)
+def test_persistent_wide_tile_kernel_forced(ctx, forced, case, grid, lx, ly):
+    from ifcb_classifier_amd import _lib
+    env = dict(IFCBK_CONV_PP3=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_BIG=0)
+    if grid:
+        env['IFCBK_CONV_PP3_GRID'] = grid
+    forced(**env)
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 31, lx, ly)
+    d = _desc(case, P, Q, LDX, LDY)
+    st = _lib.cur_stream()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, (sh, sw), (ph, pw))
+    yr.backward(dy)
+    yref = yr.detach().permute(0, 2, 3, 1)
+    xp, _ = _slice(xb, lx // 2, Cc)
+    # ---- forward + BatchNorm partial sums: two partial rows per 256-pixel tile
+    assert _kname(ctx, d, _lib.OP_CONV_FWD).startswith('conv_pp3<3, 8, 4, '), _kname(ctx, d, _lib.OP_CONV_FWD)
+    yb = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
+    yp, yv = _slice(yb, ly // 2, K)
+    mb = ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
+    assert mb == 2 * ((N * P * Q + 255) // 256)
+    part = torch.full((mb, 2, K), float('nan'), device='cuda')
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), xp, _lib.ptr(wk), yp, _lib.ptr(part), st)
+    torch.cuda.synchronize()
+    yh = yv.float().cpu()
+    assert _rel(yh, yref) < 3e-3
+    assert not torch.isnan(part).any()
+    assert torch.allclose(part[:, 0].sum(0).cpu(), yh.sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(part[:, 1].sum(0).cpu(), (yh * yh).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+    if ly:
+        assert torch.isnan(yb[..., :ly // 2].float()).all() and torch.isnan(yb[..., ly // 2 + K:].float()).all()
+    y1 = yb.clone()
+    yb.fill_(float('nan'))
+    part.fill_(float('nan'))
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), xp, _lib.ptr(wk), yp, _lib.ptr(part), st)
+    torch.cuda.synchronize()
+    assert torch.equal(yb.view(torch.int16), y1.view(torch.int16))          # bitwise repeatable (NaN padding included)
+    # ---- without statistics (a raw store only)
+    yb.fill_(float('nan'))
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), xp, _lib.ptr(wk), yp, None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(yb.view(torch.int16), y1.view(torch.int16))
+    # ---- eval epilogue: affine (+ReLU, and without)
+    g = torch.Generator().manual_seed(3)
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    scd, shd = scale.cuda(), shift.cuda()
+    for relu in (1, 0):
+        assert _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE).startswith('conv_pp3<3, 8, 4, ') and ', 1, ' in _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE)
+        y2 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
+        y2p, y2v = _slice(y2, ly // 2, K)
+        ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scd), _lib.ptr(shd), None, 0, relu, st)
+        torch.cuda.synchronize()
+        want = yref * scale + shift                              # (the affine acts on the fp32 accumulator here: one rounding)
+        if relu:
+            want = torch.relu(want)
+        assert _rel(y2v.float().cpu(), want) < 4e-3
+        if ly:
+            assert torch.isnan(y2[..., :ly // 2].float()).all() and torch.isnan(y2[..., ly // 2 + K:].float()).all()
+    if sh != 1:
+        return
+    # ---- first-writer input gradient (a conv over dy with the flipped filter)
+    assert _kname(ctx, d, _lib.OP_CONV_DGRAD).startswith('conv_pp3<3, 8, 4, '), _kname(ctx, d, _lib.OP_CONV_DGRAD)
+    dyp, _ = _slice(dyb, ly // 2, K)
+    dxb = torch.full((N, H, W, LDX), float('nan'), dtype=torch.bfloat16, device='cuda')
+    dxp, dxv = _slice(dxb, lx // 2, Cc)
+    ctx.call('ifcbk_conv2d_dgrad', C.byref(d), dyp, _lib.ptr(wT), dxp, 0, st)
+    torch.cuda.synchronize()
+    assert _rel(dxv.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < 3e-3
+    if lx:
+        assert torch.isnan(dxb[..., :lx // 2].float()).all() and torch.isnan(dxb[..., lx // 2 + Cc:].float()).all()
 
 
 # grouped weight gradients (ifcbk_conv2d_wgrad_group, round 4): members with DIFFERENT filter shapes, maps, strides, tails and slices in
