@@ -10,10 +10,9 @@
 //     addresses are switched to the next tile in that K-tile's load part;
 //   * the epilogue is register-direct and DEFERRED: at the boundary a wave packs its accumulators to bf16 (48 registers for the
 //     256 x 192 tile; BatchNorm statistics of the rounded values by DPP row reductions, or the folded eval affine + ReLU), zeroes
-//     them and goes on multiplying; the packed tile leaves as ONE 8-byte buffer store per (16 x 16 tile) in the load parts of the
-//     next tile's phases (SPP per half-phase, behind that half-phase's LDS-DMA pieces so that the counted vmcnt waits stay exact;
-//     a store slot with nothing to send issues a dropped out-of-range store, which keeps the counts compile-time constants).
-//     Only the last tile of a block has an exposed (register-direct) epilogue.
+//     them and goes on multiplying; the packed tile leaves as one burst of 8-byte buffer stores (one per 16 x 16 tile) issued
+//     behind the LDS-DMA pieces of the next tile's first phase, so that the counted vmcnt waits of the following phases do not
+//     wait for them.  Only the last tile of a block has an exposed (register-direct) epilogue.
 // Statistics: one partial row per (tile, pixel half): ifcbk_conv2d_fwd_mblocks = 2 per M tile (as conv_ws).
 //
 // Tile 256 pixels x 192 channels (MT = 8, TN = 3): 96 accumulator + 48 packed + 56 fragment registers.  Serves the plain gathers
@@ -38,7 +37,7 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 // EPI 0: raw store (+ BatchNorm statistics when a.part); EPI 1: y = act(acc * scale[n] + shift[n])
-template <int TN, int MT, int PM0, int SPP, int EPI, bool PLAIN>
+template <int TN, int MT, int PM0, int EPI, bool PLAIN>
 __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned ybytes) {
     constexpr int ES = 2, CE = 8, BK = 64;
     constexpr int PM1 = MT - PM0;
@@ -172,35 +171,24 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) packed[i][j] = u32x2_t{0u, 0u};
-    int sidx = NST;                                      // next deferred store (NST: none pending)
+    int bq = 0;                                          // 2: this phase issues the burst, 1: the phase after it, 0: no burst in flight
     unsigned yb = OOB;                                   // this lane's byte offset of (tile row frow of its half, first channel)
     unsigned nvalid = 0;                                 // bit nt: the lane's four channels of column tile nt exist
     const int rowstep16 = 16 * a.ldy * ES;
     int m0_fin = 0, n0_fin = 0, mtile_fin = 0;
 
-    // one deferred store (or a dropped one: the count per half-phase is a compile-time constant)
-#define P3_STORE_CASE(Q)                                                                                                  \
-    case (Q):                                                                                                             \
-        dat = packed[(Q) / TN][(Q) % TN];                                                                                 \
-        vo = (nvalid >> ((Q) % TN) & 1u) ? yb : OOB;                                                                      \
-        so = ((Q) / TN) * rowstep16 + ((Q) % TN) * 32;                                                                    \
-        break;
-#define P3_STORE_SLOT()                                                                                                   \
+    // the packed tile leaves in ONE straight-line burst of NST 8-byte stores (static register indices: a store slot chosen by a
+    // run-time index compiled to a branch tree that cost more than the stores), issued BEHIND the LDS-DMA pieces of the phase in
+    // which the tile is packed: the two waits that follow only cover pieces requested before the burst (their allowed-outstanding
+    // counts grow by NST), the third one -- a whole K-tile later -- is the first that has the burst in front of it
+#define P3_BURST()                                                                                                        \
     {                                                                                                                     \
-        u32x2_t dat = u32x2_t{0u, 0u};                                                                                    \
-        unsigned vo = OOB;                                                                                                \
-        int so = 0;                                                                                                       \
-        switch (sidx) {                                                                                                   \
-            P3_STORE_CASE(0) P3_STORE_CASE(1) P3_STORE_CASE(2) P3_STORE_CASE(3) P3_STORE_CASE(4) P3_STORE_CASE(5)         \
-            P3_STORE_CASE(6) P3_STORE_CASE(7) P3_STORE_CASE(8) P3_STORE_CASE(9) P3_STORE_CASE(10) P3_STORE_CASE(11)       \
-            P3_STORE_CASE(12) P3_STORE_CASE(13) P3_STORE_CASE(14) P3_STORE_CASE(15) P3_STORE_CASE(16) P3_STORE_CASE(17)   \
-            P3_STORE_CASE(18) P3_STORE_CASE(19) P3_STORE_CASE(20) P3_STORE_CASE(21) P3_STORE_CASE(22) P3_STORE_CASE(23)   \
-            default: break;                                                                                               \
-        }                                                                                                                 \
-        __builtin_amdgcn_raw_buffer_store_b64(dat, rsY, vo, so, 0);                                                   \
-        sidx = sidx < NST ? sidx + 1 : NST;                                                                               \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                             \
+                __builtin_amdgcn_raw_buffer_store_b64(packed[mt][nt], rsY, (nvalid >> nt & 1u) ? yb : OOB,                \
+                                                      mt * rowstep16 + nt * 32, 0);                                       \
     }
-    static_assert(NST == 24, "store cases");
+    static_assert(NST <= 40, "vmcnt range");
 
     f32x4_t acc[MT][TN];
 #pragma unroll
@@ -265,7 +253,6 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
         yb = (unsigned)((m0_fin + grp * HM + frow) * a.ldy + nb) * (unsigned)ES;                                          \
         nvalid = 0;                                                                                                       \
         _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) nvalid |= (nb + nt * 16 < a.K ? 1u : 0u) << nt;                 \
-        sidx = 0;                                                                                                         \
     }
 
     // ---- prologue: K-tile 0 of the first tile (even slot + filter tile, odd slot), then dropped stores that make the first
@@ -275,8 +262,6 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
     P3_ISSUE_B(0)
     P3_ISSUE_A(NA0, NA1, E_BYTES, 0)
     P3_ADVANCE_K()
-#pragma unroll
-    for (int s = 0; s < SPP; ++s) P3_STORE_SLOT()
 
     unsigned faE[2], faO[2], faB[2];
 #pragma unroll
@@ -287,7 +272,7 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
         faB[kk] = (unsigned)(size_t)(lptr_t)(smem + A_BYTES + (wc * 16 * TN + frow) * ROWB + ph);
     }
 
-    wait_vmcnt<NA1 + SPP>();                           // even slot + filter tile of K-tile 0 have landed
+    wait_vmcnt<NA1>();                                 // even slot + filter tile of K-tile 0 have landed
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
 
@@ -308,6 +293,7 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
                 if (kt == 0 && fin) {
                     P3_PACK()
                     fin = false;
+                    bq = 2;
                 }
                 const unsigned bB0 = faB[0] + par * BBUF, bB1 = faB[1] + par * BBUF;
                 const unsigned bA0 = faE[0] + par * APAR, bA1 = faE[1] + par * APAR;
@@ -341,9 +327,12 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
                 }
                 P3_ISSUE_A(0, NA0, 0, par ^ 1u)
                 P3_ISSUE_B(par ^ 1u)
-#pragma unroll
-                for (int s = 0; s < SPP; ++s) P3_STORE_SLOT()
-                wait_vmcnt<2 * SPP + NA0 + TN>();       // everything older than the previous half-phase's stores: the odd slot of this K-tile
+                if (bq == 2) {
+                    P3_BURST()
+                    wait_vmcnt<NA0 + TN + NST>();       // the odd slot of this K-tile (requested before everything above)
+                } else {
+                    wait_vmcnt<NA0 + TN>();
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -378,9 +367,12 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
                 }
                 P3_ISSUE_A(NA0, NA1, E_BYTES, par ^ 1u)
                 P3_ADVANCE_K()
-#pragma unroll
-                for (int s = 0; s < SPP; ++s) P3_STORE_SLOT()
-                wait_vmcnt<2 * SPP + NA1>();            // the even slot and the filter tile of the next K-tile have landed
+                if (bq == 2) {
+                    wait_vmcnt<NA1 + NST>();            // the even slot and the filter tile of the next K-tile: requested before the burst
+                    bq = 0;
+                } else {
+                    wait_vmcnt<NA1>();
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -405,31 +397,32 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
         if (dead) break;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
-    // ---- the block's last tile: whatever of the tile before it is still unsent (none, by the choice of SPP), then its own tile
-#pragma unroll 1
-    while (sidx < NST) P3_STORE_SLOT()
+    // ---- the block's last tile: its stores are the only exposed ones
     P3_PACK()
-#pragma unroll 1
-    while (sidx < NST) P3_STORE_SLOT()
+    P3_BURST()
     wait_vmcnt<0>();
 #undef P3_SETUP
 #undef P3_ISSUE_A
 #undef P3_ISSUE_B
 #undef P3_ADVANCE_K
-#undef P3_STORE_CASE
-#undef P3_STORE_SLOT
+#undef P3_BURST
 #undef P3_PACK
 }
 
-// IFCBK_CONV_PP3: 0 = never, 1 = where the plan below expects a gain (default), 2 = wherever the kernel applies (tests)
+// IFCBK_CONV_PP3: 0 = never (DEFAULT), 1 = where a CU gets at least two tiles, 2 = wherever the kernel applies (tests).
+// Off by default -- measured (scripts/conv_pp3_fixedcost.py, scripts/conv_pp3_check.py): on the SAME 256 x 192 tile a block
+// that walks 8 tiles takes exactly as long as 8 conv_pp2 blocks (171.8 vs 172.3 us at 8 K-tiles per tile, 432 vs 433 at 32): the
+// 11 us a tile costs beyond its K-tiles are not launch + prologue + LDS-staged epilogue but the time its 96 KB of output need to
+// leave the CU (7-10 B/clk per CU with every CU storing at once = the chip's write bandwidth), and loads issued behind the stores
+// wait for them (vmcnt retires in order) whether the stores come as one burst or one per half-phase.
 int pp3_mode() {
     const char* e = getenv("IFCBK_CONV_PP3");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }
 
-template <int SPP, int EPI, bool PLAIN>
+template <int EPI, bool PLAIN>
 void launch_pp3(const ConvArgs& a, int ntiles, int grid, unsigned ybytes, hipStream_t st) {
-    hipLaunchKernelGGL((conv_pp3<3, 8, 4, SPP, EPI, PLAIN>), dim3((unsigned)grid), dim3(512), 0, st, a, ntiles, ybytes);
+    hipLaunchKernelGGL((conv_pp3<3, 8, 4, EPI, PLAIN>), dim3((unsigned)grid), dim3(512), 0, st, a, ntiles, ybytes);
 }
 
 }  // namespace
@@ -442,7 +435,7 @@ bool ifcbk_conv_pp3_plan(int dtype, int M, int K, int Kg, int epi) {
     if (mode <= 0 || dtype != IFCBK_BF16 || (epi != 0 && epi != 1)) return false;
     if (K % 8 || (epi == 1 && K > 2048)) return false;
     const int nk = cdiv(Kg, 64);
-    if (nk < 4) return false;                               // 24 deferred stores need 2 * nk * SPP >= 24 slots, SPP <= 3
+    if (nk < 3) return false;                               // (the burst of a tile must be out of the way before the next tile is packed)
     if (mode >= 2) return true;
     const int cus = ifcbk_num_cus();
     const int64_t tiles = (int64_t)cdiv(M, 256) * cdiv(K, 192);
@@ -460,22 +453,14 @@ int ifcbk_conv_pp3_launch(ifcbk_ctx* ctx, void* args, hipStream_t st) {
     int cus = ifcbk_num_cus();
     if (const char* e = getenv("IFCBK_CONV_PP3_GRID")) { const int f = atoi(e); if (f > 0) cus = f; }      // test hook: few blocks walk many tiles
     const int grid = (int)(ntiles < cus ? ntiles : cus);
-    const int nk = cdiv(a.Kg, 64);
-    const int spp = nk >= 12 ? 1 : nk >= 6 ? 2 : 3;
     const bool plain = a.R == 1 && a.S == 1 && a.base_h == 0 && a.base_w == 0 && a.ostr_h == 1 && a.ostr_w == 1;
-    const int epi = a.ep_scale ? 1 : 0;
-#define PP3_GO(SPPV)                                                                                       \
-    {                                                                                                      \
-        if (epi) { if (plain) launch_pp3<SPPV, 1, true>(a, (int)ntiles, grid, (unsigned)yb, st); else launch_pp3<SPPV, 1, false>(a, (int)ntiles, grid, (unsigned)yb, st); } \
-        else { if (plain) launch_pp3<SPPV, 0, true>(a, (int)ntiles, grid, (unsigned)yb, st); else launch_pp3<SPPV, 0, false>(a, (int)ntiles, grid, (unsigned)yb, st); }  \
-    }
-    if (spp == 1) PP3_GO(1) else if (spp == 2) PP3_GO(2) else PP3_GO(3)
-#undef PP3_GO
+    if (a.ep_scale) { if (plain) launch_pp3<1, true>(a, (int)ntiles, grid, (unsigned)yb, st); else launch_pp3<1, false>(a, (int)ntiles, grid, (unsigned)yb, st); }
+    else { if (plain) launch_pp3<0, true>(a, (int)ntiles, grid, (unsigned)yb, st); else launch_pp3<0, false>(a, (int)ntiles, grid, (unsigned)yb, st); }
     IFCBK_LAUNCH_CHECK(ctx, "conv_pp3");
     return 0;
 }
 
 void ifcbk_conv_pp3_name(int Kg, bool affine, bool plain, char* name, size_t cap) {
-    const int nk = cdiv(Kg, 64);
-    snprintf(name, cap, "conv_pp3<3, 8, 4, %d, %d, %s>", nk >= 12 ? 1 : nk >= 6 ? 2 : 3, affine ? 1 : 0, plain ? "true" : "false");
+    (void)Kg;
+    snprintf(name, cap, "conv_pp3<3, 8, 4, %d, %s>", affine ? 1 : 0, plain ? "true" : "false");
 }

@@ -16,7 +16,7 @@ from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
 # environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
-_DISPATCH_SWITCHES = ('IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+_DISPATCH_SWITCHES = ('IFCBK_FWD_LANES', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
                       'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
                       'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
 
@@ -832,6 +832,9 @@ class Engine:
         WLs = list(range(NL - self.wgrad_lane, NL))        # the weight-gradient lanes
         wl_next = [0]
         lane_of = assign_lanes(NL - self.wgrad_lane)
+        # the forward has no weight gradients: IFCBK_FWD_LANES lets its branches use the weight-gradient lane(s) too
+        fwd_lanes = max(1, min(NL, int(os.environ.get('IFCBK_FWD_LANES', str(NL - self.wgrad_lane)))))
+        lane_fwd = assign_lanes(fwd_lanes) if fwd_lanes != NL - self.wgrad_lane else lane_of
         lane_eval = assign_lanes(self.NL_eval)
         if not hasattr(self, 'draw_own'):
             self.draw_own = {}
@@ -873,7 +876,7 @@ class Engine:
         bwd_groups = []
         for k, n in enumerate(net.nodes):
             grp = OpList()
-            L = lane_of[n]
+            L = lane_fwd[n]
             if n.kind == 'conv':
                 M = N * n.P * n.Q
                 d = self._conv_desc(n, N)
@@ -973,7 +976,7 @@ class Engine:
                             mbnd = BnDesc(M, m.K, mld, m.y.buf.C, 1, self.cdtype, m.eps, 0.1)
                             if m.cpool is not None:
                                 # commuted pool branch: pool the conv's slice of the merged tensor, then BatchNorm the pooled tensor
-                                Lm, pn = lane_of[m], m.cpool
+                                Lm, pn = lane_fwd[m], m.cpool
                                 pre, ldpre = self._pre_ptr(m)
                                 ppd = PoolDesc(N, pn.x.H, pn.x.W, m.K, ldpre, 3, 3, 1, 1, 1, 1, pn.P, pn.Q, mld, self.cdtype)
                                 rpre, rr2 = ('gr', id(g), m.koff, m.koff + m.K), ('r', m.raw.id, 0, m.K)
@@ -996,10 +999,10 @@ class Engine:
                                     p=(_vp(self.bn_part[0], 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
                                        _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
                                        self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
-                                    i=(gmb, g.Ktot), bn=mbnd, lane=lane_of[m], reads=[rbp(0)], writes=[rst(m)])
+                                    i=(gmb, g.Ktot), bn=mbnd, lane=lane_fwd[m], reads=[rbp(0)], writes=[rst(m)])
                             lst.add(_lib.OP_BN_APPLY, m.name,
                                     p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd,
-                                    lane=lane_of[m], reads=[rraw(m), rst(m)], writes=[ra(m.y)])
+                                    lane=lane_fwd[m], reads=[rraw(m), rst(m)], writes=[ra(m.y)])
                         continue
                     if u8:
                         lst.add(_lib.OP_STEM_U8_FWD, n.name, p=(gu8, self._pptr(ckey), gab, raw, _vp(self.bn_part[L]), None, None),

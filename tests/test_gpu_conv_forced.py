@@ -277,7 +277,8 @@ PP3 = [
     ((4, 768, 17, 17, 384, 1, 1, 1, 1, 0, 0), 3, 0, 8),          # plain 1x1 GEMM (the sibling-GEMM shape), 5 M tiles x 2 N tiles, SPP 1
     ((3, 96, 23, 19, 136, 3, 3, 2, 2, 0, 0), 2, 8, 0),           # stride-2 forward, 136 of 192 channels, SPP 1 (nk = 14)
     ((5, 40, 15, 13, 72, 3, 3, 1, 1, 1, 1), 2, 0, 0),            # nk = 6: SPP 2
-    ((6, 256, 9, 9, 264, 1, 1, 1, 1, 0, 0), 0, 0, 0),            # nk = 4: SPP 3, the launch's own grid
+    ((6, 256, 9, 9, 264, 1, 1, 1, 1, 0, 0), 0, 0, 0),            # nk = 4, the launch's own grid
+    ((8, 192, 12, 12, 192, 1, 1, 1, 1, 0, 0), 2, 0, 0),          # nk = 3 (the shortest tile the burst allows), 5 tiles on 2 blocks
     ((2, 64, 40, 31, 192, 3, 3, 1, 1, 1, 1), 5, 0, 16),          # 10 tiles on 5 blocks: two tiles each
 ]
 
@@ -330,7 +331,7 @@ def test_persistent_wide_tile_kernel_forced(ctx, forced, case, grid, lx, ly):
     scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
     scd, shd = scale.cuda(), shift.cuda()
     for relu in (1, 0):
-        assert _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE).startswith('conv_pp3<3, 8, 4, ') and ', 1, ' in _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE)
+        assert _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE).startswith('conv_pp3<3, 8, 4, 1, '), _kname(ctx, d, _lib.OP_CONV_FWD_AFFINE)
         y2 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
         y2p, y2v = _slice(y2, ly // 2, K)
         ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scd), _lib.ptr(shd), None, 0, relu, st)
