@@ -15,6 +15,7 @@ struct ifcbk_ctx {
     unsigned ws_epoch;   // bumped when the arenas move: graphs captured before are stale
     hipStream_t lane_st[IFCBK_MAX_LANES];   // lanes 1.. of ifcbk_run_program (lane 0 is the caller's stream)
     int lane_low;        // bit mask of lanes whose streams get the least stream priority (ifcbk_ctx_lane_priority)
+    hipStream_t cap_st[IFCBK_MAX_LANES];    // the lanes' streams inside a stream capture: always default priority (see run_lanes)
     hipEvent_t xev[64];  // cross-lane ordering events, used round-robin
     int n_xev, xev_next;
     hipEvent_t* cev;     // ordering events of stream captures: one per edge, never reused inside a capture

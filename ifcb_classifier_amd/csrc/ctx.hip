@@ -75,8 +75,10 @@ extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     if (!c) return IFCBK_OK;
     if (c->ws_base) (void)hipFree(c->ws_base);
     if (c->zeros) (void)hipFree(c->zeros);
-    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l) {
         if (c->lane_st[l]) (void)hipStreamDestroy(c->lane_st[l]);
+        if (c->cap_st[l]) (void)hipStreamDestroy(c->cap_st[l]);
+    }
     for (int i = 0; i < c->n_xev; ++i) (void)hipEventDestroy(c->xev[i]);
     for (int i = 0; i < c->n_cev; ++i) (void)hipEventDestroy(c->cev[i]);
     free(c->cev);
@@ -306,7 +308,10 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
     if (int e = lane_resources(c, used)) return e;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if (used >> l & 1) {
-            st[l] = c->lane_st[l];
+            // Inside a stream capture the lanes run on capture-only streams of DEFAULT priority: replaying a graph that was captured
+            // through a least-priority forked stream segfaulted inside hipGraphLaunch (ROCm 7.2, reproducibly at the 136th test of
+            // the GPU suite -- never in a fresh process, never with IFCBK_LANE_LOW_PRIO=0).  A graph node carries no priority anyway.
+            st[l] = c->capturing ? c->cap_st[l] : c->lane_st[l];
             if (int e = lane_order(c, st[l], s0)) return e;                 // fork: the lane starts after the caller's prior work
         }
     int rc = IFCBK_OK;
@@ -406,6 +411,8 @@ extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, i
     int used = 1;
     for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
     if (int e = lane_resources(c, used)) return e;
+    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
+        if ((used >> l & 1) && !c->cap_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->cap_st[l], hipStreamNonBlocking));
     // one ordering event per fork / wait / join edge of this program (upper bound: 3 per op + 2 per lane)
     {
         const int need = 6 * n + 2 * IFCBK_MAX_LANES;      // (a lane-to-lane edge is recorded as two edges through the origin)
