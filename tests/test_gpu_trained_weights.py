@@ -201,8 +201,9 @@ def test_fp32_trained_weights_adam(name, nc, B, S):
 def test_bf16_trained_weights_twin(name, nc, B, S):
     """the performance mode against the bf16-STORAGE oracle, arbitrated by the same fp64 trajectory: the HIP bf16 path must be as
     close to it as the oracle's own bf16-storage arithmetic is -- its own (measured, printed) numbers, never quoted as the fp32 parity"""
-    for optimizer in ('sgd', 'adam'):
-        traj = _trajectories(name, nc, B, S, 'bf16', optimizer, arbiter=True)
+    # (inception_v3: SGD only, two steps -- every trajectory costs an fp32 and an fp64 oracle step on the host per HIP step)
+    for optimizer in (('sgd',) if name == 'inception_v3' else ('sgd', 'adam')):
+        traj = _trajectories(name, nc, B, S, 'bf16', optimizer, steps=2 if name == 'inception_v3' else 3, arbiter=True)
         _report('bf16 %s %s' % (optimizer, name), traj)
         for t in traj:
             assert t['nbt_ok']
