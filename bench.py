@@ -150,7 +150,8 @@ def run_mode_leg(args, local):
     from ifcb_classifier_amd import graph
     from ifcb_classifier_amd.engine import Engine
     POOL, BMAX = 8192, 1024
-    eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=BMAX)
+    # (an inference engine, as neuston_net RUN builds it: activations for BMAX images, gradient-side buffers for one)
+    eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=BMAX, train_batch=1)
     eng.init_weights(seed=1234)
     rois, _ = synth_rois(POOL + BMAX, 4321, eng.dev)
 
