@@ -486,13 +486,18 @@ class Engine:
         # -> BN-backward ..., and the MFMA-bound weight gradients (6.7 ms of a step when each runs alone) fill in beside the
         # HBM-bound BatchNorm / pool kernels instead of standing in front of every input gradient on its lane
         # default: ONE weight-gradient lane (the last) when there are at least 3 lanes.  Measured at batch 256, same box, ms/step:
-        # 4 chain lanes 22.67 | 3 chains + 1 weight-gradient lane 21.72 | the same with that lane's stream at low priority 21.60 |
+        # 4 chain lanes 22.67 | 3 chains + 1 weight-gradient lane 21.72 | the same with that lane's stream at low priority 21.60 (off, below) |
         # 2 + 1 lanes 22.34 | FIVE streams (4 + 1, 3 + 2) 27.7, six 31.8: this runtime has four hardware queues per process.
         # Two lanes (the data-parallel default): 2 chains 22.90 | 1 chain + 1 weight-gradient lane 22.52.
         self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '1' if self.NL >= 2 else '0'))       # number of weight-gradient lanes
         if self.NL - self.wgrad_lane < 1 or self.wgrad_side_lane:
             self.wgrad_lane = 0
-        if not self.plan_only:
+        # The weight-gradient lane's stream at the LEAST stream priority (ifcbk_ctx_lane_priority) was worth 0.0-0.1 ms per step
+        # (21.70 -> 21.60 in one A/B, 21.61 vs 21.61 in another) and is OFF: a least-priority stream changes how the runtime maps
+        # EVERY stream of the process onto its four hardware queues -- the RUN-mode engine that bench.py builds after the training
+        # leg lost 10 % at batch 512 and 5 % at 1024 while the training engine's streams existed (44.5 / 48.0 vs 49.5 / 50.4 k
+        # img/s), and replaying a hipGraph captured through such a stream segfaulted in a long-lived process.  IFCBK_WGRAD_LANE_LOW=1.
+        if not self.plan_only and os.environ.get('IFCBK_WGRAD_LANE_LOW', '0') != '0':
             low = 0
             for l in range(self.NL - self.wgrad_lane, self.NL):
                 low |= 1 << l
