@@ -150,3 +150,40 @@ def test_bin_table_is_one_pass_over_the_adc_and_views_into_one_blob(tmp_path):
     (tmp_path / (lid + '.roi')).write_bytes(blob[:-10])
     with pytest.raises(ValueError, match='past the end'):
         Bin(str(tmp_path / lid)).table
+
+
+def test_weights_file_that_needs_unpickling_is_refused_unless_trusted(tmp_path, monkeypatch):
+    """--weights reads plain state dicts with weights_only=True; a file that needs arbitrary unpickling is a full
+    checkpoint and is loaded only when the caller says it is trusted; other errors propagate (ref neuston_models.py:23-42: upstream
+    downloads torchvision's own file here)"""
+    import torch
+    from ifcb_classifier_amd import neuston_models as nm
+
+    import argparse
+    Odd = argparse.Namespace         # a global the safe unpickler does not allow (what Lightning's hyper_parameters hold)
+    good, bad = str(tmp_path / 'sd.pth'), str(tmp_path / 'ckpt.pth')
+    torch.save({'fc.weight': torch.zeros(2, 3)}, good)
+    torch.save({'state_dict': {'fc.weight': torch.zeros(2, 3)}, 'extra': Odd()}, bad)
+
+    class Backbone(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(3, 2, bias=False)
+    monkeypatch.delenv('IFCBK_TRUST_WEIGHTS', raising=False)
+    loaded, skipped = nm.load_pretrained_weights(Backbone(), good)
+    assert loaded == ['fc.weight']
+    with pytest.raises(RuntimeError, match='IFCBK_TRUST_WEIGHTS'):
+        nm.load_pretrained_weights(Backbone(), bad)
+    with pytest.raises(FileNotFoundError):
+        nm.load_pretrained_weights(Backbone(), str(tmp_path / 'missing.pth'))
+
+
+def test_bin_table_rejects_negative_sizes_and_offsets(tmp_path):
+    from ifcb_classifier_amd.ifcb_bins import Bin
+    lid = 'D20130526T092352_IFCB013'
+    cols = ['0'] * 24
+    cols[15], cols[16], cols[17] = '4', '5', '-20'
+    (tmp_path / (lid + '.adc')).write_text(','.join(cols) + '\n')
+    (tmp_path / (lid + '.roi')).write_bytes(bytes(64))
+    with pytest.raises(ValueError, match='negative'):
+        Bin(str(tmp_path / lid)).table

@@ -11,11 +11,11 @@ def _happens_before(sched):
     n = len(sched)
     last_on_lane = {}
     preds = [set() for _ in range(n)]
-    queued = {l: [] for l in range(4)}
+    queued = {l: [] for l in range(8)}
     for i, (lane, wait) in enumerate(sched):
         if lane in last_on_lane:
             preds[i].add(last_on_lane[lane])
-        for l in range(4):
+        for l in range(8):
             if wait >> l & 1 and queued[l]:
                 preds[i].add(queued[l][-1])          # the tail of lane l (stream order covers everything before it)
         last_on_lane[lane] = i
@@ -52,7 +52,7 @@ def _random_program(rng, n, nl):
 def test_schedule_orders_every_conflict():
     rng = random.Random(1234)
     for trial in range(60):
-        nl = rng.choice([1, 2, 3, 4])
+        nl = rng.choice([1, 2, 3, 4, 6, 8])
         meta = _random_program(rng, rng.randrange(5, 70), nl)
         sched = schedule_lanes(meta)
         assert len(sched) == len(meta)
@@ -74,3 +74,36 @@ def test_schedule_orders_every_conflict():
 def test_single_lane_program_has_no_waits():
     meta = [(0, [('a', 0, 0, 8)], [('a', 1, 0, 8)]), (0, [('a', 1, 0, 8)], [('a', 2, 0, 8)]), (0, None, None)]
     assert schedule_lanes(meta) == [(0, 0), (0, 0), (0, 0)]
+
+
+def test_weight_gradients_have_their_own_lane_and_wait_for_their_operands():
+    """round 4: in the REAL backward list of inception_v3 (Engine(plan_only=True)) every weight gradient -- single launches, the
+    sibling GEMMs' segmented ones, the grouped launches -- sits on the last lane, every layer's d(raw) lives in a buffer of its own,
+    and the schedule orders each weight gradient behind the BatchNorm backward that writes its dy (and a grouped one behind ALL
+    its members').  ref neuston_models.py:81-86: autograd computes the same gradients wherever it likes before optimizer.step()."""
+    from ifcb_classifier_amd import graph, _lib
+    from ifcb_classifier_amd.engine import Engine
+    eng = Engine(graph.build('inception_v3', 7), max_batch=2, plan_only=True)
+    assert eng.NL == 4 and eng.wgrad_lane == 1
+    pl = eng.plan(2)
+    ops, meta = pl.bwd_list.ops, pl.bwd_list.meta
+    sched = schedule_lanes(meta)
+    reach = _happens_before(sched)
+    wkinds = (_lib.OP_CONV_WGRAD, _lib.OP_CONV_WGRAD_SEG, _lib.OP_CONV_WGRAD_GROUP, _lib.OP_STEM_U8_WGRAD)
+    nw = 0
+    for j, o in enumerate(ops):
+        if o.kind in wkinds:
+            nw += 1
+            assert sched[j][0] == eng.NL - 1, pl.bwd_list.tags[j]
+            # every d(raw) resource it reads was written by an earlier op that happens-before it
+            for r in meta[j][1]:
+                if r[0] in ('drawn', 'dg'):
+                    writers = [i for i in range(j) if meta[i][2] and any(_overlap(w, r) for w in meta[i][2])]
+                    assert writers, (pl.bwd_list.tags[j], r)
+                    assert all(i in reach[j] for i in writers), (pl.bwd_list.tags[j], r)
+        else:
+            assert sched[j][0] != eng.NL - 1 or o.kind == 0, pl.bwd_list.tags[j]
+    assert nw >= 40
+    # no two layers share a d(raw) buffer any more
+    ptrs = [t.data_ptr() for t in eng.draw_own.values()]
+    assert len(ptrs) == len(set(ptrs)) and len(ptrs) >= 60          # (the sibling GEMMs' members share their group's merged tensor)
