@@ -409,15 +409,17 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
 #undef P3_PACK
 }
 
-// IFCBK_CONV_PP3: 0 = never (DEFAULT), 1 = where a CU gets at least two tiles, 2 = wherever the kernel applies (tests).
-// Off by default -- measured (scripts/conv_pp3_fixedcost.py, scripts/conv_pp3_check.py): on the SAME 256 x 192 tile a block
-// that walks 8 tiles takes exactly as long as 8 conv_pp2 blocks (171.8 vs 172.3 us at 8 K-tiles per tile, 432 vs 433 at 32): the
-// 11 us a tile costs beyond its K-tiles are not launch + prologue + LDS-staged epilogue but the time its 96 KB of output need to
-// leave the CU (7-10 B/clk per CU with every CU storing at once = the chip's write bandwidth), and loads issued behind the stores
-// wait for them (vmcnt retires in order) whether the stores come as one burst or one per half-phase.
+// IFCBK_CONV_PP3: 0 = never, 1 = the measured niche (DEFAULT), 2 = wherever the kernel applies (tests).
+// Measured (scripts/conv_pp3_fixedcost.py, scripts/conv_pp3_check.py): on the SAME 256 x 192 tile a block that walks 8
+// tiles takes exactly as long as 8 conv_pp2 blocks (171.8 vs 172.3 us at 8 K-tiles per tile, 432 vs 433 at 32): the 11 us a tile
+// costs beyond its K-tiles are not launch + prologue + LDS-staged epilogue but the time its 96 KB of output need to leave the CU
+// (7-10 B/clk per CU with every CU storing at once = the chip's write bandwidth), and loads issued behind the stores wait for them
+// (vmcnt retires in order).  So training never takes it.  The niche is the EVAL forward of a large RUN batch, whose affine epilogue
+// has no statistics to reduce: where conv_pp2 would run this very tile (MT 8, TN 3: the 8x8 layers at batch >= 768) it is 1.00-1.10x,
+// on the 320 x 192 layers from ~4.5 tiles per CU on 1.01-1.03x; the RUN forward at batch 1024: 50.1 -> 51.5 k img/s.
 int pp3_mode() {
     const char* e = getenv("IFCBK_CONV_PP3");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
 }
 
 template <int EPI, bool PLAIN>
@@ -437,10 +439,13 @@ bool ifcbk_conv_pp3_plan(int dtype, int M, int K, int Kg, int epi) {
     const int nk = cdiv(Kg, 64);
     if (nk < 3) return false;                               // (the burst of a tile must be out of the way before the next tile is packed)
     if (mode >= 2) return true;
+    if (epi != 1) return false;                             // training forward / input gradients: never (see pp3_mode)
+    int bmt = 0, btn = 0;
+    if (!ifcbk_conv_big_plan(dtype, M, K, Kg, &bmt, &btn) || btn != 3) return false;      // only where conv_pp2 would run 192-channel tiles
     const int cus = ifcbk_num_cus();
     const int64_t tiles = (int64_t)cdiv(M, 256) * cdiv(K, 192);
-    const double waste = (double)cdiv(K, 192) * 192 / K;
-    return tiles >= 2 * cus && waste <= 1.2;
+    if ((double)cdiv(K, 192) * 192 / K > 1.2) return false;
+    return bmt == 8 ? tiles >= 2 * cus : tiles >= 4 * cus;
 }
 
 int ifcbk_conv_pp3_launch(ifcbk_ctx* ctx, void* args, hipStream_t st) {

@@ -92,7 +92,7 @@ WIDE = [
 @pytest.mark.parametrize('case,mt,tn,lx,ly', WIDE)
 def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, lx, ly):
     from ifcb_classifier_amd import _lib
-    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)
+    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)      # (conv_pp3 has its own test below)
     if mt:
         env.update(IFCBK_CONV_BIG_MT=mt, IFCBK_CONV_BIG_TN=tn)
     forced(**env)
