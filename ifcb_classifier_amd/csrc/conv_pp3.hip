@@ -214,6 +214,11 @@ __global__ __launch_bounds__(512) void conv_pp3(ConvArgs a, int ntiles, unsigned
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                           \
                 f32x4_t v = acc[mt][nt];                                                                                  \
                 if (EPI == 1) {                                                                                           \
+                    /* the affine acts on the conv output AS STORED (rounded to bf16), like conv_epilogue_store: the same  \
+                       bits whichever kernel the batch size selects */                                                     \
+                    const unsigned r01 = pack2bf(v[0], v[1]), r23 = pack2bf(v[2], v[3]);                                  \
+                    v[0] = __uint_as_float(r01 << 16); v[1] = __uint_as_float(r01 & 0xffff0000u);                         \
+                    v[2] = __uint_as_float(r23 << 16); v[3] = __uint_as_float(r23 & 0xffff0000u);                         \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
                         v[j] = v[j] * sc[j] + sh[j];                                                                      \
                         if (a.ep_relu) v[j] = fmaxf(v[j], 0.f);                                                           \

@@ -336,10 +336,19 @@ def test_persistent_wide_tile_kernel_forced(ctx, forced, case, grid, lx, ly):
         y2p, y2v = _slice(y2, ly // 2, K)
         ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y2p, _lib.ptr(scd), _lib.ptr(shd), None, 0, relu, st)
         torch.cuda.synchronize()
-        want = yref * scale + shift                              # (the affine acts on the fp32 accumulator here: one rounding)
+        want = _bf(yref) * scale + shift                         # the affine acts on the conv output as stored (rounded), as in conv_pp2
         if relu:
             want = torch.relu(want)
         assert _rel(y2v.float().cpu(), want) < 4e-3
+        # ... bit for bit what the LDS-staged epilogue of conv_pp2 / conv_igemm writes: a RUN batch gets the same scores whichever
+        # kernel its size selects
+        forced(IFCBK_CONV_PP3=0, IFCBK_CONV_FLAT=0)
+        y3 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
+        y3p, y3v = _slice(y3, ly // 2, K)
+        ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y3p, _lib.ptr(scd), _lib.ptr(shd), None, 0, relu, st)
+        torch.cuda.synchronize()
+        assert torch.equal(y3v, y2v)
+        forced(**env)
         if ly:
             assert torch.isnan(y2[..., :ly // 2].float()).all() and torch.isnan(y2[..., ly // 2 + K:].float()).all()
     if sh != 1:
