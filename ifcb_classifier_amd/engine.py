@@ -192,6 +192,13 @@ class Engine:
         self.requested_batch = int(max_batch)
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
         self.window_batch = max(1, ((1 << 31) - 1) // per_img)
+        # ... and the element-wise kernels (pools, layout, preprocess) index a tensor with 32-bit element counts: a batch whose
+        # largest activation has 2^31 elements or more is refused outright (inception_v3: 1,552 images; measured: batch 2048 ran
+        # and returned WRONG probabilities before this guard existed)
+        self.index_batch = max(1, ((1 << 31) - 1) // max(b.H * b.W * b.C for b in net.bufs))
+        if int(max_batch) > self.index_batch:
+            raise RuntimeError('max_batch %d: the largest activation of %s would hold 2^31 elements or more (limit %d images per batch)'
+                               % (int(max_batch), net.name, self.index_batch))
         self.max_batch = int(max_batch)
         # capacity of the TRAINING-side buffers (activation gradients, d(raw) scratch, pool arg-max, split-K workspace): a training
         # step beyond the window is refused anyway, so they never need more than it; an inference-only engine (neuston_net RUN:
