@@ -160,6 +160,12 @@ class Program:
 class Engine:
     """Device state of one model replica."""
 
+    @staticmethod
+    def capacity_limit(net, dtype='bf16'):
+        """the largest batch one engine serves (see __init__: largest activation <= 3 GiB)"""
+        per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
+        return max(1, (3 << 30) // per_img)
+
     def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16', optimizer='adam',
                  momentum=0.0, plan_only=False, train_batch=None):
         # plan_only: build buffers on the host and the op tables only (no HIP context, nothing can run) -- the CPU tests
@@ -192,13 +198,15 @@ class Engine:
         self.requested_batch = int(max_batch)
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
         self.window_batch = max(1, ((1 << 31) - 1) // per_img)
-        # ... and the element-wise kernels (pools, layout, preprocess) index a tensor with 32-bit element counts: a batch whose
-        # largest activation has 2^31 elements or more is refused outright (inception_v3: 1,552 images; measured: batch 2048 ran
-        # and returned WRONG probabilities before this guard existed)
-        self.index_batch = max(1, ((1 << 31) - 1) // max(b.H * b.W * b.C for b in net.bufs))
+        # ... and an eval batch beyond that window is verified bit for bit against its parts only up to 1024 inception images (largest
+        # activation 2.83 GB: tests/test_gpu_model.py).  Measured past it: batch 1536 ended in a GPU memory fault and batch 2048
+        # returned WRONG probabilities (some kernel outside the convolutions' image-group path still addresses with 32 bits) -- so
+        # the engine refuses a capacity whose largest activation exceeds 3 GiB (inception_v3 bf16: 1,164 images) instead of finding
+        # out on the device.  RUN chunks a larger --batch itself.
+        self.index_batch = max(1, (3 << 30) // per_img)
         if int(max_batch) > self.index_batch:
-            raise RuntimeError('max_batch %d: the largest activation of %s would hold 2^31 elements or more (limit %d images per batch)'
-                               % (int(max_batch), net.name, self.index_batch))
+            raise RuntimeError('max_batch %d: the largest activation of %s would exceed 3 GiB; batches beyond %d images are not '
+                               'supported in one program (run them in chunks)' % (int(max_batch), net.name, self.index_batch))
         self.max_batch = int(max_batch)
         # capacity of the TRAINING-side buffers (activation gradients, d(raw) scratch, pool arg-max, split-K workspace): a training
         # step beyond the window is refused anyway, so they never need more than it; an inference-only engine (neuston_net RUN:

@@ -56,6 +56,11 @@ class HipBackbone(nn.Module):
     def __init__(self, net, device=0, max_batch=None, dtype='bf16', **engine_kw):
         super().__init__()
         max_batch = max_batch or 32
+        cap = Engine.capacity_limit(net, dtype)
+        if max_batch > cap:
+            # (neuston_net RUN --batch 2048: results are per image, the RUN loop cuts its batches to what the engine holds)
+            print('%s: batch capacity %d -> %d images per program (largest activation <= 3 GiB)' % (net.name, max_batch, cap))
+            max_batch = cap
         object.__setattr__(self, 'engine', Engine(net, device, max_batch, dtype=dtype, **engine_kw))
         object.__setattr__(self, 'net', net)
         eng = self.engine

@@ -355,6 +355,8 @@ def do_run(args):
             raise argparse.ArgumentTypeError('Must be at least one KEYWORD')
     classifier = NeustonModel.load_from_checkpoint(args.MODEL, device=int(os.environ.get('LOCAL_RANK', 0)),
                                                    max_batch=args.batch_size, inference=True)
+    if args.batch_size > classifier.model.engine.max_batch:
+        args.batch_size = classifier.model.engine.max_batch          # per-image results: a smaller program batch changes nothing
     seed_everything(classifier.hparams.seed)
     # (a RUN batch beyond the 2 GiB buffer-descriptor window needs nothing here: results are per image, and the library cuts the
     #  convolutions of such a batch into launches over image groups)
