@@ -182,8 +182,10 @@ def _check(opt, name, traj, loss_tol):
     uw, um, ww, bb = STEP1[(opt, name)]
     t = traj[0]
     assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
+    assert abs(t['loss_h'] - t['loss_o']) < 1e-4 * abs(t['loss_o'])          # same weights, same batch: measured 6e-7
     for t in traj:
         assert t['nbt_ok']
+        # (from step 2 on the loss is evaluated on weights that already differ by the chaotic update distances above: 9e-3 at batch 8)
         assert abs(t['loss_h'] - t['loss_o']) < loss_tol * abs(t['loss_o'])
         assert _arbitrated(t)
 
@@ -192,7 +194,7 @@ def _check(opt, name, traj, loss_tol):
 def test_fp32_trained_weights_sgd(name, nc, B, S, steps):
     traj = _trajectories(name, nc, B, S, 'fp32', 'sgd', steps=steps, arbiter=True)
     _report('fp32 SGD(0.005, m=0.9) ' + name, traj)
-    _check('sgd', name, traj, 5e-3)
+    _check('sgd', name, traj, 4e-2)
 
 
 @pytest.mark.parametrize('name,nc,B,S,steps', CASES)
