@@ -859,9 +859,28 @@ class Engine:
         if not hasattr(self, 'draw_own'):
             self.draw_own = {}
 
+        def _carve(nelem):
+            """a d(raw) buffer out of ONE pooled allocation per engine (78 tensors of an inception plan: one hipMalloc instead of 78,
+            not zero-filled -- BatchNorm backward writes every element before anything reads it)"""
+            if getattr(self, '_draw_pool', None) is None:
+                tot = 0
+                for m in self.convs:
+                    if m.group is None or m.cpool is not None:
+                        tot += (self.train_batch * m.P * m.Q * m.K + 127) // 128 * 128
+                for gq in self.groups:
+                    tot += (self.train_batch * gq.x.H * gq.x.W * gq.Ktot + 127) // 128 * 128
+                self._draw_pool = torch.empty(max(tot, 128), dtype=self.tdtype, device=self.dev)
+                self._draw_used = 0
+            n = (nelem + 127) // 128 * 128
+            if self._draw_used + n > self._draw_pool.numel():
+                return torch.empty(nelem, dtype=self.tdtype, device=self.dev)
+            v = self._draw_pool[self._draw_used:self._draw_used + nelem]
+            self._draw_used += n
+            return v
+
         def own_draw(m):
             if m not in self.draw_own:
-                self.draw_own[m] = torch.zeros(self.train_batch * m.P * m.Q * m.K, dtype=self.tdtype, device=self.dev)
+                self.draw_own[m] = _carve(self.train_batch * m.P * m.Q * m.K)
             return self.draw_own[m]
 
         def group_draw(gq):
@@ -869,7 +888,7 @@ class Engine:
             if not self.wgrad_lane:
                 return self.draw_group
             if getattr(gq, 'draw_own', None) is None:
-                gq.draw_own = torch.zeros(self.train_batch * gq.x.H * gq.x.W * gq.Ktot, dtype=self.tdtype, device=self.dev)
+                gq.draw_own = _carve(self.train_batch * gq.x.H * gq.x.W * gq.Ktot)
             return gq.draw_own
 
         # ---- resources for the lane scheduler: channel ranges of tensors
