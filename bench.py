@@ -149,7 +149,7 @@ def run_mode_leg(args, local):
     does not depend on the pixel values).  Batch sweep on 100 k ROIs each, then the full count at the best batch size."""
     from ifcb_classifier_amd import graph
     from ifcb_classifier_amd.engine import Engine
-    POOL, BMAX = 8192, 1024
+    POOL, BMAX = 8192, 2048
     # (an inference engine, as neuston_net RUN builds it: activations for BMAX images, gradient-side buffers for one)
     eng = Engine(graph.build('inception_v3', args.classes, pretrained=False), device=local, max_batch=BMAX, train_batch=1)
     eng.init_weights(seed=1234)
@@ -193,7 +193,7 @@ def run_mode_leg(args, local):
         return nb * B / dt, 1e3 * dt / nb, nb * B
 
     sweep = {}
-    for B in (256, 512, 768, 1024):      # 1024: beyond the 776-image descriptor window of one launch (convolutions run as two image groups)
+    for B in (256, 512, 768, 1024, 2048):      # from 1024 on beyond the 776-image descriptor window of one launch (convolutions run over image groups)
         ips, ms, n = run(B, 100000)
         sweep[str(B)] = dict(images_per_s=round(ips, 1), ms_per_batch=round(ms, 3), rois=n)
     best = max(sweep, key=lambda b: sweep[b]['images_per_s'])

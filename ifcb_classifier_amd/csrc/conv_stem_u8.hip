@@ -335,8 +335,10 @@ __global__ __launch_bounds__(256) void stem_u8_fwd_mfma_kernel(StemArgs a) {
         const unsigned skip = grp == a.gpr - 1 ? ovl : 0u;        // pixels of this group that the previous group already covered
         // group base (wave-uniform -> scalar registers): pixel row * Q + first pixel of the group, channel 0
         const size_t gbase = ((size_t)row * a.Q + grp * 32 - skip) * a.ld * 2;
-        uint8_t* yb = (uint8_t*)a.y + (((size_t)__builtin_amdgcn_readfirstlane((unsigned)(gbase >> 32)) << 32) |
-                                       (size_t)__builtin_amdgcn_readfirstlane((unsigned)gbase));
+        // (readfirstlane returns int: without the unsigned casts the low half sign-extends once the offset passes 2 GiB -- 1,511
+        //  images of 149 x 149 x 32 -- and the rows of the later images land 4 GiB in front of the tensor)
+        uint8_t* yb = (uint8_t*)a.y + (((size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(gbase >> 32)) << 32) |
+                                       (size_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)gbase));
         unsigned short ob[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {

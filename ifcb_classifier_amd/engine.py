@@ -157,14 +157,25 @@ class Program:
         return arr
 
 
+# The largest activation an engine may hold: that of the largest batch an eval program was verified on, bit for bit against its
+# 256-image parts over every activation (scripts/big_batch_bisect.py: 4,096 inception_v3 images, 147 x 147 x 64 bf16 each).
+VERIFIED_ACTIVATION_BYTES = 4096 * 147 * 147 * 64 * 2
+
+
+def _index_bytes():
+    # development switch (scripts/big_batch_bisect.py): another cap, to look beyond the verified one
+    e = os.environ.get('IFCBK_DEV_INDEX_GIB')
+    return int(float(e) * (1 << 30)) if e else VERIFIED_ACTIVATION_BYTES
+
+
 class Engine:
     """Device state of one model replica."""
 
     @staticmethod
     def capacity_limit(net, dtype='bf16'):
-        """the largest batch one engine serves (see __init__: largest activation <= 3 GiB)"""
+        """the largest batch one engine serves (see __init__: largest activation <= VERIFIED_ACTIVATION_BYTES)"""
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
-        return max(1, (3 << 30) // per_img)
+        return max(1, _index_bytes() // per_img)
 
     def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16', optimizer='adam',
                  momentum=0.0, plan_only=False, train_batch=None):
@@ -198,15 +209,17 @@ class Engine:
         self.requested_batch = int(max_batch)
         per_img = max(b.H * b.W * b.C for b in net.bufs) * (2 if dtype == 'bf16' else 4)
         self.window_batch = max(1, ((1 << 31) - 1) // per_img)
-        # ... and an eval batch beyond that window is verified bit for bit against its parts only up to 1024 inception images (largest
-        # activation 2.83 GB: tests/test_gpu_model.py).  Measured past it: batch 1536 ended in a GPU memory fault and batch 2048
-        # returned WRONG probabilities (some kernel outside the convolutions' image-group path still addresses with 32 bits) -- so
-        # the engine refuses a capacity whose largest activation exceeds 3 GiB (inception_v3 bf16: 1,164 images) instead of finding
-        # out on the device.  RUN chunks a larger --batch itself.
-        self.index_batch = max(1, (3 << 30) // per_img)
+        # ... and an eval batch beyond that window is verified bit for bit against its parts up to 4,096 inception images, every
+        # activation compared (scripts/big_batch_bisect.py; tests/test_gpu_model.py at 1024 and across the 2 GiB offset of the stem
+        # output).  Round 4 had capped this at 3 GiB after batch 1536 faulted and batch 2048 returned wrong probabilities: the u8
+        # stem kernel sign-extended the low half of its 64-bit row offset (readfirstlane returns int), so the rows of images
+        # >= 1,511 were written 4 GiB in front of the tensor -- fixed in csrc/conv_stem_u8.hip.  The engine still refuses a
+        # capacity beyond what was verified instead of finding out on the device; RUN chunks a larger --batch itself.
+        self.index_batch = max(1, _index_bytes() // per_img)
         if int(max_batch) > self.index_batch:
-            raise RuntimeError('max_batch %d: the largest activation of %s would exceed 3 GiB; batches beyond %d images are not '
-                               'supported in one program (run them in chunks)' % (int(max_batch), net.name, self.index_batch))
+            raise RuntimeError('max_batch %d: the largest activation of %s would exceed the verified %.1f GiB; batches beyond %d '
+                               'images are not supported in one program (run them in chunks)'
+                               % (int(max_batch), net.name, _index_bytes() / (1 << 30), self.index_batch))
         self.max_batch = int(max_batch)
         # capacity of the TRAINING-side buffers (activation gradients, d(raw) scratch, pool arg-max, split-K workspace): a training
         # step beyond the window is refused anyway, so they never need more than it; an inference-only engine (neuston_net RUN:

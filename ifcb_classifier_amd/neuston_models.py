@@ -59,7 +59,7 @@ class HipBackbone(nn.Module):
         cap = Engine.capacity_limit(net, dtype)
         if max_batch > cap:
             # (neuston_net RUN --batch 2048: results are per image, the RUN loop cuts its batches to what the engine holds)
-            print('%s: batch capacity %d -> %d images per program (largest activation <= 3 GiB)' % (net.name, max_batch, cap))
+            print('%s: batch capacity %d -> %d images per program (largest verified activation)' % (net.name, max_batch, cap))
             max_batch = cap
         object.__setattr__(self, 'engine', Engine(net, device, max_batch, dtype=dtype, **engine_kw))
         object.__setattr__(self, 'net', net)

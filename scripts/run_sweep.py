@@ -12,7 +12,7 @@ from ifcb_classifier_amd import graph
 from ifcb_classifier_amd.engine import Engine
 
 POOL, BMAX = 8192, int(os.environ.get("SWEEP_BMAX", "1024"))
-eng = Engine(graph.build('inception_v3', 100, pretrained=False), device=0, max_batch=BMAX)
+eng = Engine(graph.build('inception_v3', 100, pretrained=False), device=0, max_batch=BMAX, train_batch=1)
 eng.init_weights(seed=1234)
 rois, _ = bench.synth_rois(POOL + BMAX, 4321, eng.dev)
 for B in [int(v) for v in os.environ.get("SWEEP_BATCHES", "256,512,768,1024,512,1024").split(",")]:

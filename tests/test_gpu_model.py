@@ -352,6 +352,33 @@ def test_batch_beyond_the_descriptor_window_is_one_eval_program_and_refused_in_t
 
 
 @pytest.mark.gpu
+def test_roi_batch_whose_stem_output_passes_2_gib_equals_its_parts():
+    """RUN path (ragged u8 ROIs -> resized plane -> u8 stem kernel -> hipGraph-replayed eval forward -> softmax) at 1,536 images:
+    Conv2d_1a's output is 2.18 GB, Conv2d_4a's runs as two image groups.  Probabilities equal those of the same ROIs run 256 at
+    a time, bit for bit (round 4: this batch size faulted -- csrc/conv_stem_u8.hip, the sign-extended row offset)."""
+    import bench
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    B = 1536
+    eng = Engine(graph.build('inception_v3', 20, pretrained=False), device=0, max_batch=B, train_batch=1)
+    eng.init_weights(seed=4)
+    rois, _ = bench.synth_rois(B, 31, eng.dev)
+
+    def run(i0, n):
+        eng.load_rois(rois['pixels'], rois['offs'][i0:i0 + n], rois['hs'][i0:i0 + n], rois['ws'][i0:i0 + n], rois['max_h'], rois['max_w'])
+        p = eng.forward_eval(n)
+        eng.run(p.softmax)
+        torch.cuda.synchronize()
+        return eng.probs[:n].clone()
+    run(0, B)
+    whole = run(0, B)
+    parts = torch.cat([run(i, 256) for i in range(0, B, 256)], 0)
+    assert torch.isfinite(whole).all() and torch.equal(whole, parts)
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_lane_count_does_not_change_the_result(monkeypatch):
     """The lane count only decides which stream a kernel is launched on (data-parallel jobs use 2 lanes, a single GPU 4, one
     lane is plain stream order): every reduction has a fixed order and the per-lane scratch buffers carry no state, so

@@ -91,6 +91,42 @@ def test_stem_u8_kernels_vs_fp64_conv_of_the_three_affine_planes(N, H, W, dtype)
     assert torch.equal(dw2, base + dw)
 
 
+def test_stem_u8_rows_beyond_the_2_gib_offset_of_the_output():
+    """1,520 images of 149 x 149 x 32 bf16 are 2.16 GB: the rows of images >= 1,511 start beyond byte 2^31 of the output.  The
+    MFMA kernel builds a row's address from two readfirstlane halves; round 4 found the low half sign-extended there (the rows
+    were written 4 GiB in front of the tensor: a RUN batch of 1,536 faulted, one of 2,048 returned wrong probabilities).  The
+    last images of the big launch must equal the same images run on their own, and the tensor in front of them stays intact."""
+    from ifcb_classifier_amd import _lib
+    from ifcb_classifier_amd._lib import ConvDesc
+    ctx = _lib.Context(0)
+    st = _lib.cur_stream()
+    N, H, W, K, n_tail = 1520, 299, 299, 32, 24
+    P = Q = 149
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    g = torch.randint(0, 256, (N, H, W), device='cuda', generator=gen, dtype=torch.uint8)
+    w = torch.randn(K, 3, 3, 3, device='cuda', generator=gen) * 0.2
+    ab = torch.tensor(_ab((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), device='cuda', dtype=torch.float32)
+    scale = torch.rand(K, device='cuda', generator=gen) + 0.5
+    shift = torch.randn(K, device='cuda', generator=gen) * 0.3
+    assert (N - n_tail) * P * Q * K * 2 < (1 << 31) < N * P * Q * K * 2
+    y = torch.zeros(N, P, Q, K, device='cuda', dtype=torch.bfloat16)
+    d = ConvDesc(N, H, W, 8, 8, K, 3, 3, 2, 2, 0, 0, P, Q, K, 3, _lib.BF16)
+    ctx.call('ifcbk_stem_u8_fwd', C.byref(d), _lib.ptr(g), _lib.ptr(w), _lib.ptr(ab), _lib.ptr(y), None, _lib.ptr(scale), _lib.ptr(shift), 1, st)
+    torch.cuda.synchronize()
+    i0 = N - n_tail
+    y2 = torch.zeros(n_tail, P, Q, K, device='cuda', dtype=torch.bfloat16)
+    d2 = ConvDesc(n_tail, H, W, 8, 8, K, 3, 3, 2, 2, 0, 0, P, Q, K, 3, _lib.BF16)
+    ctx.call('ifcbk_stem_u8_fwd', C.byref(d2), _lib.ptr(g[i0:]), _lib.ptr(w), _lib.ptr(ab), _lib.ptr(y2), None, _lib.ptr(scale), _lib.ptr(shift), 1, st)
+    torch.cuda.synchronize()
+    assert y2.float().abs().sum().item() > 0
+    assert torch.equal(y[i0:], y2)
+    y3 = torch.zeros(8, P, Q, K, device='cuda', dtype=torch.bfloat16)
+    d3 = ConvDesc(8, H, W, 8, 8, K, 3, 3, 2, 2, 0, 0, P, Q, K, 3, _lib.BF16)
+    ctx.call('ifcbk_stem_u8_fwd', C.byref(d3), _lib.ptr(g), _lib.ptr(w), _lib.ptr(ab), _lib.ptr(y3), None, _lib.ptr(scale), _lib.ptr(shift), 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:8], y3)
+
+
 def test_stem_u8_refuses_what_it_does_not_serve():
     from ifcb_classifier_amd import _lib
     from ifcb_classifier_amd._lib import ConvDesc
