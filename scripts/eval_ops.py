@@ -7,7 +7,7 @@ from ifcb_classifier_amd import graph, _lib
 from ifcb_classifier_amd.engine import Engine
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-eng = Engine(graph.build('inception_v3', 100, pretrained=False), device=0, max_batch=B)
+eng = Engine(graph.build('inception_v3', 100, pretrained=False), device=0, max_batch=B, train_batch=1)
 eng.init_weights(seed=1)
 rois, _ = bench.synth_rois(B, 1, eng.dev)
 eng.load_rois(**rois)
@@ -30,7 +30,7 @@ for i in range(prog.n):
     eng.ctx.lib.ifcbk_op_cost(C.byref(o), C.byref(fl), C.byref(by))
     rows.append({'i': i, 'tag': prog.tags[i], 'op': _lib.OP_NAMES.get(o.kind, str(o.kind)), 'kernel': name.value.decode(),
                  'ms': acc[i], 'gflop': fl.value / 1e9, 'mbytes': by.value / 1e6})
-json.dump(rows, open('gpurun_out/eval_ops.json', 'w'))
+json.dump(rows, open('gpurun_out/eval_ops_%d.json' % B, 'w'))
 by = collections.defaultdict(lambda: [0, 0, 0, 0])
 for r in rows:
     b = by[r['op']]; b[0] += r['ms']; b[1] += r['gflop']; b[2] += r['mbytes']; b[3] += 1
