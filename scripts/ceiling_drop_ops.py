@@ -58,6 +58,18 @@ def match(o, cls):
         return k in (_lib.OP_BN_BWD, _lib.OP_BN_BWD_PARTIALS, _lib.OP_BN_BWD_MAXPOOL)
     if cls == 'bnapply':
         return k in (_lib.OP_BN_APPLY, _lib.OP_BN_APPLY_MAXPOOL)
+    if cls in ('dgrad35', 'dgrad17', 'dgrad8', 'dgradstem'):
+        if k not in (_lib.OP_CONV_DGRAD, _lib.OP_CONV_DGRAD_BNSTAT, _lib.OP_CONV_DGRAD_BNSTAT_TAB):
+            return False
+        hw = d.H                        # the tensor the input gradient is written for
+        return {'dgrad35': hw == 35, 'dgrad17': hw == 17, 'dgrad8': hw == 8, 'dgradstem': hw > 35}[cls]
+    if cls in ('fwd35', 'fwd17', 'fwd8', 'fwdstem'):
+        if k not in (_lib.OP_CONV_FWD, _lib.OP_STEM_U8_FWD):
+            return False
+        hw = d.P
+        return {'fwd35': hw == 35, 'fwd17': hw == 17, 'fwd8': hw == 8, 'fwdstem': hw > 35}[cls]
+    if cls == 'pools':
+        return k in (_lib.OP_MAXPOOL_FWD, _lib.OP_MAXPOOL_BWD, _lib.OP_AVGPOOL_FWD, _lib.OP_AVGPOOL_BWD)
     if cls == 'fwdconv':
         return k in (_lib.OP_CONV_FWD, _lib.OP_STEM_U8_FWD)
     raise SystemExit('unknown class ' + cls)
