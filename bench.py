@@ -319,27 +319,70 @@ def free_port():
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched the
     GPU and never will: no torch.cuda call, no library load -- nothing re-execs a process that initialised HIP), relay rank 0's
-    JSON line unchanged as the LAST stdout line, everything else to stderr, and return the children's exit code."""
+    JSON line unchanged as the LAST stdout line, everything else to stderr, and return the children's exit code.
+    The launcher and its ranks run in a process group of their own: if this process is told to stop (SIGTERM / SIGINT / any
+    exception) the whole group is terminated and reaped -- no GPU rank is left behind as an orphan.  The rendezvous port is
+    picked by bind-and-close, which another job on the box can win in between: a launcher that dies on "address already in use"
+    is started again on a fresh port (at most 3 times); any other failure is final."""
+    import signal
     import subprocess
-    cmd = launch_argv(n, argv, free_port())
-    print('[bench] --gpus %d without WORLD_SIZE: starting the ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    import threading
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
-    line = None
-    for ln in proc.stdout:
-        t = ln.strip()
-        if t.startswith('{') and '"metric"' in t:
+
+    def on_term(signum, frame):
+        raise SystemExit(128 + signum)
+    old = {sg: signal.signal(sg, on_term) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        for attempt in range(3):
+            cmd = launch_argv(n, argv, free_port())
+            print('[bench] --gpus %d without WORLD_SIZE: starting the ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+            port_taken = [False]
+
+            def relay_err():
+                for ln in proc.stderr:
+                    if 'EADDRINUSE' in ln or 'ddress already in use' in ln:
+                        port_taken[0] = True
+                    sys.stderr.write(ln)
+                    sys.stderr.flush()
+            th = threading.Thread(target=relay_err, daemon=True)
+            th.start()
+            line = None
             try:
-                json.loads(t)
-                line = t
+                for ln in proc.stdout:
+                    t = ln.strip()
+                    if t.startswith('{') and '"metric"' in t:
+                        try:
+                            json.loads(t)
+                            line = t
+                            continue
+                        except ValueError:
+                            pass
+                    sys.stderr.write(ln)
+                    sys.stderr.flush()
+                rc = proc.wait()
+                th.join(timeout=5)
+            finally:
+                if proc.poll() is None:                      # we are being stopped: take the ranks with us
+                    try:
+                        os.killpg(proc.pid, signal.SIGTERM)
+                        try:
+                            proc.wait(timeout=15)
+                        except subprocess.TimeoutExpired:
+                            os.killpg(proc.pid, signal.SIGKILL)
+                            proc.wait()
+                    except ProcessLookupError:
+                        pass
+            if rc != 0 and line is None and port_taken[0] and attempt < 2:
+                print('[bench] the rendezvous port was taken by another job; starting the ranks again on a fresh port',
+                      file=sys.stderr, flush=True)
                 continue
-            except ValueError:
-                pass
-        sys.stderr.write(ln)
-        sys.stderr.flush()
-    rc = proc.wait()
+            break
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
     if line is not None:
         print(line, flush=True)
     elif rc == 0:
@@ -365,6 +408,8 @@ def rehearse(args, rank, world):
     exchange, mode = make_exchange(dist)
     eng.G.fill_(float(rank + 1))
     dist.barrier()
+    if os.environ.get('IFCBK_REHEARSE_SLEEP'):          # test hook: ranks that live long enough to be killed (launcher clean-up test)
+        time.sleep(float(os.environ['IFCBK_REHEARSE_SLEEP']))
     t0 = time.perf_counter()
     for _ in range(max(1, min(args.steps, 3))):
         eng.G.fill_(float(rank + 1))
@@ -383,7 +428,10 @@ def rehearse(args, rank, world):
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'REHEARSAL on CPU (IFCBK_BENCH_REHEARSE=1): rendezvous, bucket plan and exchange only, no GPU work',
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'rank_devices': devs,
-                       'exchange': mode, 'buckets': [int(s[3] - s[2]) for s in segs]},
+                       'exchange': mode, 'buckets': [int(s[3] - s[2]) for s in segs], 'IFCBK_LANES': eng.NL,
+                       'program_lanes': eng.NL, 'weight_gradient_lanes': eng.wgrad_lane},
+            'single_gpu_same_lanes_ms': None,
+            'single_gpu_same_lanes_note': 'rehearsal: nothing is measured (a GPU run times 10 local steps at the DP lane count here)',
             'rehearsal': True, 'exchange_sums_ok': ok, 'cpu_baseline': None,
             'cpu_baseline_reason': 'rehearsal: nothing is measured'}), flush=True)
     dist.barrier()
@@ -553,6 +601,26 @@ def main():
                 ev_dom[sl] = eng.plan(B).step.timed(domops)
             eng._select_slot(cur)
     torch.cuda.synchronize()
+    # N > 1: the single-GPU step at THIS job's program-lane count (a DP job defaults to 2 lanes, the N = 1 bench to 4), timed on
+    # every rank before the DP loop -- 10 local steps, no exchange -- so that (single_gpu_same_lanes_ms / DP ms per step) separates
+    # the cost of communication from the cost of the lane change in the first scaling curve.  Every replica is then put back on
+    # rank 0's state.
+    single_same_lanes_ms = None
+    if world > 1:
+        for k in range(13):
+            if k == 3:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+            eng.load_rois(**rois)
+            eng.train_step(B)
+        torch.cuda.synchronize()
+        single_same_lanes_ms = 1e2 * (time.perf_counter() - tl)
+        for buf in (eng.P, eng.M, eng.V, eng.RB):
+            dist.broadcast(buf, 0)
+        eng.params_changed()
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -655,7 +723,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'inception_v3 100-class bf16 TRAIN, batch %d per GPU, synthetic u8 ROIs h,w~U{32..299} '
                                    'resized on-GPU to 299x299 (BASELINE.json configs[1])' % B,
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'program_lanes': eng.NL, 'optimizer': 'adam lr=1e-3',
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'program_lanes': eng.NL, 'IFCBK_LANES': eng.NL,
+                       'weight_gradient_lanes': eng.wgrad_lane, 'optimizer': 'adam lr=1e-3',
                        'rank_devices': rank_devices,
                        'loss': 'CE + 0.4*CE_aux',
                        'input_pipeline': ('preprocess of batch k+1 on a side stream beside step k (two input slots); one preprocess + '
@@ -672,6 +741,9 @@ def main():
                                'note': 'fp32 sum of the flat gradient, one bucket per backward segment, launched behind the segment '
                                        'that completes it; exposed = HIP-event pair around the waits behind the last segment, rank 0, '
                                        'mean over the timed steps (IFCBK_DP_EXCHANGE=allreduce|rsag)'}
+            out['single_gpu_same_lanes_ms'] = round(single_same_lanes_ms, 3)
+            out['single_gpu_same_lanes_note'] = ('rank 0, 10 local train steps (preprocess + fused step, no exchange) at this job\'s %d program '
+                                                 'lanes, timed before the DP loop: efficiency of the exchange alone = this / ms_per_step' % eng.NL)
             out['cpu_baseline'] = None
             out['cpu_baseline_reason'] = 'N > 1: the CPU reference is timed on rank 0 of the N = 1 run only (bench contract)'
         if pcie:

@@ -19,6 +19,7 @@ if os.environ.get('IFCBK_LIB'):
     LIB_PATH = _alt
 
 BF16, F32 = 0, 1
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4        # include/ifcbk.h
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_WEIGHT_PACK, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_BWD,
  OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_HEAD_FWD, OP_HEAD_BWD,
@@ -92,7 +93,8 @@ _PROTOS = {
     'ifcbk_ctx_destroy': (_i, [_vp]),
     'ifcbk_ctx_reserve': (_i, [_vp, _sz]),
     'ifcbk_ctx_workspace_bytes': (_sz, [_vp]),
-    'ifcbk_ctx_lane_priority': (_i, [_vp, _i]),
+    'ifcbk_ctx_set_lanes': (_i, [_vp, _i]),
+    'ifcbk_ctx_live_graphs': (_i, [_vp]),
     'ifcbk_last_error': (C.c_char_p, [_vp]),
     'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -220,11 +222,18 @@ class Context:
     def graph_launch(self, g, stream):
         self.call('ifcbk_graph_launch', g, stream)
 
+    def live_graphs(self):
+        return int(self.lib.ifcbk_ctx_live_graphs(self.h)) if self.h else 0
+
+    def close(self):
+        """destroy the context: its graphs first (the library's lifetime rule), then arenas, lane streams and events"""
+        if getattr(self, 'h', None):
+            self.lib.ifcbk_ctx_destroy(self.h)
+            self.h = None
+
     def __del__(self):
         try:
-            if getattr(self, 'h', None):
-                self.lib.ifcbk_ctx_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
@@ -239,6 +248,9 @@ class PlanOnlyContext:
         self.device = None
 
     def reserve(self, nbytes):
+        pass
+
+    def close(self):
         pass
 
     def call(self, name, *args):

@@ -11,11 +11,13 @@ struct ifcbk_ctx {
     int device;
     void* ws;            // workspace arena of the lane that is launching (split-K slabs, BN partials, resize tables)
     size_t ws_bytes;     // per lane
-    void* ws_base;       // IFCBK_MAX_LANES arenas of ws_bytes each
+    void* ws_base;       // ws_lanes arenas of ws_bytes each
+    int ws_lanes;        // program lanes that own an arena (ifcbk_ctx_set_lanes; programs that use a lane beyond it are refused)
     unsigned ws_epoch;   // bumped when the arenas move: graphs captured before are stale
     hipStream_t lane_st[IFCBK_MAX_LANES];   // lanes 1.. of ifcbk_run_program (lane 0 is the caller's stream)
-    int lane_low;        // bit mask of lanes whose streams get the least stream priority (ifcbk_ctx_lane_priority)
-    hipStream_t cap_st[IFCBK_MAX_LANES];    // the lanes' streams inside a stream capture: always default priority (see run_lanes)
+    hipStream_t cap_st[IFCBK_MAX_LANES];    // the lanes' streams inside a stream capture (never used to launch)
+    struct ifcbk_graph* graphs;             // every live graph captured through this ctx (the ctx owns them: ifcbk_ctx_destroy
+    int n_graphs;                           // destroys what the caller left -- a graph never outlives the arenas, streams and events it was built from)
     hipEvent_t xev[64];  // cross-lane ordering events, used round-robin
     int n_xev, xev_next;
     hipEvent_t* cev;     // ordering events of stream captures: one per edge, never reused inside a capture

@@ -58,6 +58,7 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     ifcbk_ctx* c = (ifcbk_ctx*)calloc(1, sizeof(ifcbk_ctx));
     if (!c) return IFCBK_ENOMEM;
     c->device = device;
+    c->ws_lanes = 4;
     const char* what = "hipSetDevice";
     e = hipSetDevice(device);
     if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc(&c->zeros, 4096); }
@@ -71,8 +72,13 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     return IFCBK_OK;
 }
 
+static void graph_free(ifcbk_ctx* c, ifcbk_graph* g);
+
 extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     if (!c) return IFCBK_OK;
+    // Lifetime rule: a graph's kernel nodes point into this ctx's arenas and were ordered through its capture streams and
+    // events, so no graph outlives its ctx -- whatever the caller did not destroy goes first, before anything it refers to.
+    while (c->graphs) graph_free(c, c->graphs);
     if (c->ws_base) (void)hipFree(c->ws_base);
     if (c->zeros) (void)hipFree(c->zeros);
     for (int l = 1; l < IFCBK_MAX_LANES; ++l) {
@@ -102,7 +108,7 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
     c->ws = c->ws_base = nullptr;
     c->ws_bytes = 0;
     bytes = (bytes + 255) & ~(size_t)255;
-    IFCBK_HIP(c, hipMalloc(&c->ws_base, bytes * IFCBK_MAX_LANES));     // one arena per program lane
+    IFCBK_HIP(c, hipMalloc(&c->ws_base, bytes * (size_t)c->ws_lanes));     // one arena per program lane in use
     c->ws = c->ws_base;
     c->ws_bytes = bytes;
     ++c->ws_epoch;
@@ -111,19 +117,16 @@ extern "C" int ifcbk_ctx_reserve(ifcbk_ctx* c, size_t bytes) {
 
 extern "C" size_t ifcbk_ctx_workspace_bytes(ifcbk_ctx* c) { return c ? c->ws_bytes : 0; }
 
-extern "C" int ifcbk_ctx_lane_priority(ifcbk_ctx* c, int low_mask) {
-    if (!c || low_mask < 0 || (low_mask & 1) || low_mask >= (1 << IFCBK_MAX_LANES)) return IFCBK_EINVAL;      // lane 0 is the caller's stream
-    if (low_mask == c->lane_low) return IFCBK_OK;
-    IFCBK_HIP(c, hipSetDevice(c->device));
-    for (int l = 1; l < IFCBK_MAX_LANES; ++l)
-        if (c->lane_st[l] && (((low_mask ^ c->lane_low) >> l) & 1)) {      // the stream exists with the other priority: make it anew
-            IFCBK_HIP(c, hipStreamSynchronize(c->lane_st[l]));
-            IFCBK_HIP(c, hipStreamDestroy(c->lane_st[l]));
-            c->lane_st[l] = nullptr;
-        }
-    c->lane_low = low_mask;
+extern "C" int ifcbk_ctx_set_lanes(ifcbk_ctx* c, int lanes) {
+    if (!c || lanes < 1 || lanes > IFCBK_MAX_LANES) return IFCBK_EINVAL;
+    if (lanes == c->ws_lanes) return IFCBK_OK;
+    if (c->ws_base && lanes > c->ws_lanes)
+        IFCBK_FAIL(c, IFCBK_EINVAL, "ctx_set_lanes: %d arenas are reserved; set the lane count before ifcbk_ctx_reserve", c->ws_lanes);
+    if (!c->ws_base) c->ws_lanes = lanes;      // (fewer lanes than reserved: keep the arenas, nothing to do)
     return IFCBK_OK;
 }
+
+extern "C" int ifcbk_ctx_live_graphs(ifcbk_ctx* c) { return c ? c->n_graphs : 0; }
 
 extern "C" const char* ifcbk_last_error(ifcbk_ctx* c) { return c ? c->err : g_create_err; }
 
@@ -260,27 +263,8 @@ static int lane_resources(ifcbk_ctx* c, int used) {
         for (int i = c->n_xev; i < 64; ++i) IFCBK_HIP(c, hipEventCreateWithFlags(&c->xev[i], hipEventDisableTiming));
         c->n_xev = 64;
     }
-    // lanes of c->lane_low (ifcbk_ctx_lane_priority; IFCBK_LANE_LOW_PRIO=<digits> overrides, "0" = none) get the LEAST stream
-    // priority: the engine's weight-gradient lane -- its kernels are off the critical path and yield CUs to the input-gradient chain
-    static int envlow = -2;
-    if (envlow == -2) {
-        envlow = -1;
-        if (const char* e = getenv("IFCBK_LANE_LOW_PRIO")) {
-            envlow = 0;
-            for (; *e; ++e) if (*e >= '1' && *e <= '7') envlow |= 1 << (*e - '0');
-        }
-    }
-    const int low = envlow >= 0 ? envlow : c->lane_low;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
-        if ((used >> l & 1) && !c->lane_st[l]) {
-            if (low >> l & 1) {
-                int least = 0, greatest = 0;
-                IFCBK_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                IFCBK_HIP(c, hipStreamCreateWithPriority(&c->lane_st[l], hipStreamNonBlocking, least));
-            } else {
-                IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
-            }
-        }
+        if ((used >> l & 1) && !c->lane_st[l]) IFCBK_HIP(c, hipStreamCreateWithFlags(&c->lane_st[l], hipStreamNonBlocking));
     return IFCBK_OK;
 }
 
@@ -305,12 +289,12 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
     hipStream_t st[IFCBK_MAX_LANES] = {s0};
     int used = 1;
     for (int i = 0; i < n; ++i) used |= 1 << op_lane(&ops[i]);
+    if (used >> c->ws_lanes) IFCBK_FAIL(c, IFCBK_EINVAL, "run_program: an op names a lane beyond the %d this ctx has arenas for (ifcbk_ctx_set_lanes)", c->ws_lanes);
     if (int e = lane_resources(c, used)) return e;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)
         if (used >> l & 1) {
-            // Inside a stream capture the lanes run on capture-only streams of DEFAULT priority: replaying a graph that was captured
-            // through a least-priority forked stream segfaulted inside hipGraphLaunch (ROCm 7.2, reproducibly at the 136th test of
-            // the GPU suite -- never in a fresh process, never with IFCBK_LANE_LOW_PRIO=0).  A graph node carries no priority anyway.
+            // Inside a stream capture the lanes run on capture-only streams: a stream that launches real work is never part of a
+            // capture, so nothing a graph was recorded through is ever synchronised, re-created or given work later on.
             st[l] = c->capturing ? c->cap_st[l] : c->lane_st[l];
             if (int e = lane_order(c, st[l], s0)) return e;                 // fork: the lane starts after the caller's prior work
         }
@@ -397,12 +381,30 @@ extern "C" int ifcbk_program_times(ifcbk_ctx* c, int slot, int n, float* op_ms) 
 }
 
 // ---------------------------------------------------------------- hipGraph replay
+// Lifetime rule (round 5 audit of the round-4 hipGraphLaunch SIGSEGV): every graph is OWNED by the ctx it was captured
+// through -- linked into ctx->graphs, launched and destroyed only through that ctx (checked), and destroyed by ifcbk_ctx_destroy
+// before the arenas, streams and events it refers to.  Before this rule, handles the caller dropped leaked their hipGraphExec
+// (with the runtime's per-exec parallel streams) for the life of the process.
 struct ifcbk_graph {
+    unsigned magic;              // 0x69666b67 while live
+    ifcbk_ctx* owner;
+    ifcbk_graph *prev, *next;
     hipGraph_t graph;
     hipGraphExec_t exec;
     unsigned ws_epoch;
     int n_ops;
 };
+constexpr unsigned GRAPH_MAGIC = 0x69666b67u;
+
+static void graph_free(ifcbk_ctx* c, ifcbk_graph* g) {
+    if (g->prev) g->prev->next = g->next; else c->graphs = g->next;
+    if (g->next) g->next->prev = g->prev;
+    --c->n_graphs;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    g->magic = 0; g->owner = nullptr;
+    free(g);
+}
 
 extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, ifcbk_graph** out) {
     if (!c || !out || !ops || n <= 0) return IFCBK_EINVAL;
@@ -456,24 +458,29 @@ extern "C" int ifcbk_program_capture(ifcbk_ctx* c, const ifcbk_op* ops, int n, i
         (void)hipGraphDestroy(g);
         IFCBK_FAIL(c, IFCBK_ENOMEM, "program_capture: out of host memory");
     }
+    r->magic = GRAPH_MAGIC; r->owner = c;
     r->graph = g; r->exec = x; r->ws_epoch = c->ws_epoch; r->n_ops = n;
+    r->next = c->graphs;
+    if (c->graphs) c->graphs->prev = r;
+    c->graphs = r;
+    ++c->n_graphs;
     *out = r;
     return IFCBK_OK;
 }
 
 extern "C" int ifcbk_graph_launch(ifcbk_ctx* c, ifcbk_graph* g, void* stream) {
     if (!c || !g) return IFCBK_EINVAL;
+    if (g->magic != GRAPH_MAGIC || g->owner != c) IFCBK_FAIL(c, IFCBK_EINVAL, "graph_launch: not a live graph of this ctx");
     if (g->ws_epoch != c->ws_epoch) IFCBK_FAIL(c, IFCBK_EINVAL, "graph_launch: the workspace moved since this graph was captured; capture it again");
     IFCBK_HIP(c, hipGraphLaunch(g->exec, (hipStream_t)stream));
     return IFCBK_OK;
 }
 
 extern "C" int ifcbk_graph_destroy(ifcbk_ctx* c, ifcbk_graph* g) {
-    (void)c;
     if (!g) return IFCBK_OK;
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
-    free(g);
+    if (!c) return IFCBK_EINVAL;
+    if (g->magic != GRAPH_MAGIC || g->owner != c) IFCBK_FAIL(c, IFCBK_EINVAL, "graph_destroy: not a live graph of this ctx");
+    graph_free(c, g);
     return IFCBK_OK;
 }
 

@@ -178,7 +178,10 @@ class Engine:
         return max(1, _index_bytes() // per_img)
 
     def __init__(self, net, device=0, max_batch=32, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dtype='bf16', optimizer='adam',
-                 momentum=0.0, plan_only=False, train_batch=None):
+                 momentum=0.0, plan_only=False, train_batch=None, dp_world=None):
+        # dp_world: world size of the data-parallel job this replica belongs to (None: WORLD_SIZE of the launcher, else an
+        # initialised torch.distributed group, else 1) -- it picks the program-lane default, and train_step_ddp checks it
+        self._dp_world_arg = None if dp_world is None else int(dp_world)
         # plan_only: build buffers on the host and the op tables only (no HIP context, nothing can run) -- the CPU tests
         # of the data-parallel bucket plan read the REAL backward list of a network this way
         self.plan_only = bool(plan_only)
@@ -491,14 +494,24 @@ class Engine:
         # world-1 all-reduce launches no RCCL ring kernels, so that run cannot show the lanes competing with them for CUs and
         # hardware queues (main + 4 lanes + RCCL = 6 streams on 4 queues).  No multi-GPU node was available to this build: the
         # conservative count ships, IFCBK_LANES overrides it, bench.py prints the count in `config.program_lanes`.
-        dp_world = 1
-        try:
-            import torch.distributed as _d
-            if _d.is_available() and _d.is_initialized():
-                dp_world = _d.get_world_size()
-        except Exception:
+        # world size: the explicit argument, else the launcher's WORLD_SIZE (set before any rank builds its engine, so every rank
+        # agrees whether or not init_process_group has run yet), else an initialised process group
+        dp_world = self._dp_world_arg
+        if dp_world is None:
+            try:
+                dp_world = int(os.environ.get('WORLD_SIZE', '0')) or None
+            except ValueError:
+                dp_world = None
+        if dp_world is None:
             dp_world = 1
-        self.dp_world = dp_world
+            try:
+                import torch.distributed as _d
+                if _d.is_available() and _d.is_initialized():
+                    dp_world = _d.get_world_size()
+            except Exception:
+                dp_world = 1
+        self.dp_world = max(1, int(dp_world))
+        dp_world = self.dp_world
         self.NL = max(1, min(8, int(os.environ.get('IFCBK_LANES', '2' if dp_world > 1 else '4'))))
         self.NL_eval = max(1, min(self.NL, int(os.environ.get('IFCBK_LANES_EVAL', '2'))))     # ... of the eval forward (measured best)
         # hipGraph replay of the static programs.  Measured on MI355X (B=256): the eval forward replays 1.8 % faster than its
@@ -520,16 +533,9 @@ class Engine:
         self.wgrad_lane = int(os.environ.get('IFCBK_WGRAD_LANE', '1' if self.NL >= 2 else '0'))       # number of weight-gradient lanes
         if self.NL - self.wgrad_lane < 1 or self.wgrad_side_lane:
             self.wgrad_lane = 0
-        # The weight-gradient lane's stream at the LEAST stream priority (ifcbk_ctx_lane_priority) was worth 0.0-0.1 ms per step
-        # (21.70 -> 21.60 in one A/B, 21.61 vs 21.61 in another) and is OFF: a least-priority stream changes how the runtime maps
-        # EVERY stream of the process onto its four hardware queues -- the RUN-mode engine that bench.py builds after the training
-        # leg lost 10 % at batch 512 and 5 % at 1024 while the training engine's streams existed (44.5 / 48.0 vs 49.5 / 50.4 k
-        # img/s), and replaying a hipGraph captured through such a stream segfaulted in a long-lived process.  IFCBK_WGRAD_LANE_LOW=1.
-        if not self.plan_only and os.environ.get('IFCBK_WGRAD_LANE_LOW', '0') != '0':
-            low = 0
-            for l in range(self.NL - self.wgrad_lane, self.NL):
-                low |= 1 << l
-            self.ctx.call('ifcbk_ctx_lane_priority', low & ~1)
+        # (round 4's least-priority stream for that lane -- 0.0-0.1 ms per step -- is gone: round 5)
+        if not self.plan_only:
+            self.ctx.call('ifcbk_ctx_set_lanes', self.NL)     # one workspace arena per lane in use (was: always 8)
         max_raw = max([n.P * n.Q * n.K for n in self.convs] + [8])
         # d(raw) scratch: per lane; two per lane when the weight gradient runs on the side lane (it keeps reading one while
         # the next node's BN backward already fills the other)
@@ -1403,7 +1409,7 @@ class Engine:
                             lane=L if LW is None else LW, reads=[ra(n.x)] + rdraw, writes=[])
                 else:
                     bwd.add(_lib.OP_CONV_WGRAD, n.name, p=(self._aptr(n.x), draw, self._pptr(ckey, 'G')), conv=dbw,
-                            lane=LW if LW is not None else ((L + 1) % NL if (self.wgrad_side_lane and n.P * n.Q >= self.side_min_pix) else L),
+                            lane=LW if LW is not None else ((L + 1) % NL if self.wgrad_side_lane else L),
                             reads=[ra(n.x)] + rdraw, writes=[])
                 if needs_dgrad:
                     assert n.x.is_full
@@ -1547,6 +1553,10 @@ class Engine:
         """data-parallel step: gradient all-reduce (sum) of each finished tail bucket is launched right after
         the backward segment that completes it and overlaps the remaining backward; Adam divides by world."""
         self._check_train_batch(N)
+        if int(world) != self.dp_world and 'IFCBK_LANES' not in os.environ:
+            raise RuntimeError('train_step_ddp(world=%d): this engine chose its program lanes for world %d (built before the process '
+                               'group existed and without WORLD_SIZE?); pass dp_world=%d to Engine or set IFCBK_LANES'
+                               % (int(world), self.dp_world, int(world)))
         pl = self.plan(N)
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
@@ -1558,6 +1568,30 @@ class Engine:
         self.run(pl.adam_pack)                    # (Adam, repack, and the step's counters: nbt += 1, loss_sum += loss)
         self.eval_stats_ready = False
         return pl
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        """destroy every captured graph of this engine, then its library context (arenas, lane streams, events).  The library
+        enforces the same order by itself (a ctx owns its graphs); doing it here keeps the handles in ``pl.graphs`` from dangling."""
+        ctx = getattr(self, 'ctx', None)
+        if ctx is None or getattr(ctx, 'h', None) is None:
+            return
+        for pl in getattr(self, '_plans', {}).values():
+            for g in pl.graphs.values():
+                ctx.lib.ifcbk_graph_destroy(ctx.h, g)
+            pl.graphs.clear()
+        for c in (getattr(self, 'pre_ctx', None), ctx):
+            if c is not None:
+                c.close()
+
+    def plan_graph_handles(self):
+        return [g for pl in self._plans.values() for g in pl.graphs.values()]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ execution
     def stream(self):

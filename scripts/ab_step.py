@@ -2,7 +2,7 @@
 """same-box A/B of engine switches: runs `bench.py --train-only --no-cpu-baseline --no-events` once per environment given on the
 command line (';'-separated KEY=VAL lists, '-' = defaults), interleaved ROUNDS times, and prints ms/step per configuration.
 
-    python scripts/ab_step.py 2 - IFCBK_WGRAD_GROUP=0 'IFCBK_WGRAD_LANE=1;IFCBK_LANE_LOW_PRIO=3'
+    python scripts/ab_step.py 2 - IFCBK_WGRAD_GROUP=0 'IFCBK_WGRAD_LANE=1;IFCBK_LANES=3'
 """
 import json
 import os

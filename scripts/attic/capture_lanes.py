@@ -5,7 +5,7 @@ replays the captured graph and compares it with the plain launch list.
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault('IFCBK_SEGV_BACKTRACE', '1')
 nl = os.environ.get('IFCBK_LANES_CAP', '4')
 os.environ['IFCBK_LANES'] = nl

@@ -1,6 +1,6 @@
 """dev tool (timing only): conv_big with the pixel and/or filter operand's loads dropped (IFCBK_DEBUG_DROP=a|b|ab)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc

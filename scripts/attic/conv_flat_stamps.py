@@ -1,6 +1,6 @@
 """dev tool: s_memtime stamps of conv_flat's phases (library built with -DIFCBK_EXPERIMENT_FLAT, IFCBK_FLAT_STAMPS=1)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc

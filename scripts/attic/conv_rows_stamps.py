@@ -1,7 +1,7 @@
 """dev tool: s_memtime stamps of conv_rows3x3's per-row phases (a library whose conv_rows.hip was built with the stamp patch, IFCBK_LIB):
 prologue, A = wait for the row DMA + barrier, B = MFMAs + C-row write, C = barrier, D = epilogue; wave 0 of every block, summed per block."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc

@@ -1,6 +1,6 @@
 """experiment: do two independent kernels of the step overlap when issued on two streams? (wave-quantization / tail recovery)"""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc, BnDesc

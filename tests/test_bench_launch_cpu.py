@@ -42,6 +42,32 @@ def test_gpus2_without_launcher_starts_two_ranks_and_relays_one_line(exchange):
     assert out['cpu_baseline'] is None and out['cpu_baseline_reason']
     assert sum(out['config']['buckets']) > 24_000_000 and 2 <= len(out['config']['buckets']) <= 9
     assert 'torch.distributed.run' in p.stderr           # the launcher said what it started
+    # the first scaling curve must be readable: the DP lane count and the single-GPU step at that lane count are in the line
+    # (a rehearsal measures nothing, so the value is null -- the FIELD is what the driver's parser relies on)
+    assert 'single_gpu_same_lanes_ms' in out and out['single_gpu_same_lanes_note']
+    assert out['config']['IFCBK_LANES'] == 2 and out['config']['weight_gradient_lanes'] == 1      # WORLD_SIZE=2 -> the DP default
+
+
+def test_the_launcher_takes_its_ranks_with_it_when_it_is_terminated():
+    """a driver that kills `bench.py --gpus N` must not leave the N ranks running as orphans"""
+    import signal
+    import time
+    p = subprocess.Popen([sys.executable, BENCH, '--gpus', '2', '--steps', '2', '--warmup', '0'], env=_env(IFCBK_REHEARSE_SLEEP='120'),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    pids = set()
+    t0 = time.time()
+    while time.time() - t0 < 120 and len(pids) < 2:          # wait until both ranks exist (children of torch.distributed.run)
+        time.sleep(1.0)
+        out = subprocess.run(['ps', '-eo', 'pid,args'], stdout=subprocess.PIPE, text=True).stdout
+        pids = {int(ln.split()[0]) for ln in out.splitlines() if BENCH in ln and 'torch.distributed.run' not in ln
+                and int(ln.split()[0]) != p.pid}
+    assert len(pids) >= 2, 'the ranks never started'
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    assert p.returncode != 0
+    time.sleep(2.0)
+    alive = [q for q in pids if os.path.exists('/proc/%d' % q) and 'Z' not in open('/proc/%d/stat' % q).read().split(')')[-1].split()[0]]
+    assert not alive, 'orphaned ranks: %s' % alive
 
 
 def test_a_failing_rank_fails_the_launcher():

@@ -320,6 +320,55 @@ def test_hipgraph_replay_equals_plain_launches(name, B, S, lanes, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_a_graph_belongs_to_its_ctx_and_dies_with_it():
+    """The lifetime rule behind round 4's hipGraphLaunch SIGSEGV audit: every captured graph is owned by the ctx it was
+    captured through.  (a) it is counted there; (b) another ctx can neither launch nor destroy it; (c) Engine.close() -- and
+    ifcbk_ctx_destroy by itself -- destroys the graphs BEFORE the arenas / streams / events they refer to, so that no
+    hipGraphExec outlives an engine (before round 5 every dropped handle leaked its exec for the life of the process: 135
+    engines into the GPU suite is where the crash hit); (d) a destroyed handle is refused, not dereferenced."""
+    import ctypes as C
+    from ifcb_classifier_amd import graph, _lib
+    from ifcb_classifier_amd.engine import Engine
+    eng = Engine(graph.build('resnet18', 3, pretrained=False), device=0, max_batch=4)
+    eng.graph_eval = eng.graph_train = True
+    eng.init_weights(seed=1)
+    other = _lib.Context(0)
+    assert eng.ctx.live_graphs() == 0
+    eng.load_input_nchw(torch.rand(4, 3, 224, 224).cuda())
+    eng.target[:4].copy_(torch.tensor([0, 1, 2, 1]))
+    eng.train_step(4)
+    eng.forward_eval(4)
+    torch.cuda.synchronize()
+    assert eng.ctx.live_graphs() == 2
+    g = eng.plan(4).graphs['fwd_eval']
+    assert other.lib.ifcbk_graph_launch(other.h, g, eng.stream()) == _lib.EINVAL          # (b)
+    assert b'not a live graph of this ctx' in other.lib.ifcbk_last_error(other.h)
+    assert other.lib.ifcbk_graph_destroy(other.h, g) == _lib.EINVAL
+    assert eng.ctx.live_graphs() == 2
+    eng.forward_eval(4)                                                                   # still launchable through its owner
+    torch.cuda.synchronize()
+    lib, h = eng.ctx.lib, eng.ctx.h
+    eng.close()                                                                           # (c)
+    assert eng.ctx.h is None and not eng.plan_graph_handles()
+    # (c) without the engine's help: the ctx destroys what the caller left
+    ctx2 = _lib.Context(0)
+    ops = (_lib.Op * 1)()
+    ops[0].kind = _lib.OP_MEMSET
+    buf = torch.zeros(64, device='cuda')
+    ops[0].p[0] = buf.data_ptr()
+    ops[0].i[0], ops[0].i[1] = 64, 0
+    g2 = ctx2.capture(ops, 1)
+    assert ctx2.live_graphs() == 1
+    ctx2.graph_launch(g2, _lib.cur_stream())
+    torch.cuda.synchronize()
+    assert lib.ifcbk_graph_destroy(ctx2.h, g2) == 0 and ctx2.live_graphs() == 0
+    g3 = ctx2.capture(ops, 1)
+    assert ctx2.live_graphs() == 1 and g3
+    ctx2.close()                                                                          # g3 goes with it: no leak, no dangling exec
+    other.close()
+
+
+@pytest.mark.gpu
 def test_batch_beyond_the_descriptor_window_is_one_eval_program_and_refused_in_training():
     """The conv kernels address a tensor through a 32-bit buffer descriptor: 776 inception_v3 images (bf16) fit the 2 GiB window of
     ONE launch.  An eval batch beyond it (SURVEY 8(d) config 4 sweeps batch 1024) is still one program / one hipGraph: the library

@@ -161,27 +161,40 @@ def _arbitrated(t):
 
 
 # fp32 parity mode, FIRST step (before the trajectories' own chaos compounds): update rel (worst tensor, median), weight rel, BN
-# buffers.  Measured on MI355X at batch 16 (HIP vs fp32 oracle | the fp32 oracle ITSELF vs its fp64 twin):
-#   SGD  inception_v3  3.3e-2 / 2.3e-2 | 2.8e-2 / 1.8e-2       resnet18  7.4e-3 / 3.7e-3 | 1.1e-2 / 2.9e-3
-#   Adam inception_v3  4.3e-1 / 1.6e-1 | 3.5e-1 / 1.4e-1       resnet18  2.5e-1 / 9.3e-4 | 2.5e-1 / 1.2e-4
-# (Adam's first step is -lr * sign(g): a tensor whose gradient is at rounding-noise level flips whole elements.)  After step 1 the
-# fp32 and fp64 ORACLES drift apart by 0.55 and 0.77 of the update (inception, SGD steps 2 and 3), and so does everything else:
-# from step 2 on only the arbitrated bound means anything.  bf16 storage: both the HIP path and the bf16-storage oracle sit 1.3
-# (inception) / 0.4-0.7 (resnet18) of the update away from the fp64 trajectory from the FIRST step on -- equal to each other within 5 %.
-STEP1 = {('sgd', 'inception_v3'): (1.5e-1, 8e-2, 1.5e-1, 1e-4), ('sgd', 'resnet18'): (2e-2, 1e-2, 2e-2, 1e-5),
-         ('adam', 'inception_v3'): (0.9, 0.3, 0.9, 1e-4), ('adam', 'resnet18'): (0.6, 5e-3, 0.6, 1e-5)}
+# buffers.  Measured on MI355X at the default sizes below (HIP vs fp32 oracle | the fp32 oracle ITSELF vs its fp64 twin):
+#   SGD  inception_v3 (batch 8)   3.4e-2 / 2.3e-2 / 3.4e-2 / 3.5e-6 | 3.7e-2 / 2.0e-2      resnet18 (batch 16)  7.4e-3 / 3.7e-3 / 5.4e-3 / 7.7e-8 | 1.1e-2 / 2.9e-3
+#   Adam inception_v3             4.3e-1 / 1.6e-1                   | 3.5e-1 / 1.4e-1      resnet18             2.5e-1 / 9.3e-4                   | 2.5e-1 / 1.2e-4
+# SGD: absolute first-step bounds at 2 x the measured values.  Adam gets NO absolute bound (round 4's (0.9, 0.3, 0.9) passed a 90 %
+# update error: vacuous): its first step is -lr * sign(g), so a tensor whose gradient is at rounding-noise level flips whole
+# elements in ANY arithmetic -- the fp32 reference itself sits 0.35 from its fp64 twin -- and the only statement with teeth is the
+# arbitrated one (_arbitrated: HIP no farther from the fp64 trajectory than ARB x the fp32 reference is), asserted at every step.
+# After step 1 the fp32 and fp64 ORACLES drift apart by 0.55 and 0.77 of the update (inception, SGD steps 2 and 3), and so does
+# everything else: from step 2 on only the arbitrated bound means anything for either optimizer.  bf16 storage: both the HIP path
+# and the bf16-storage oracle sit 1.3 (inception) / 0.4-0.7 (resnet18) of the update away from the fp64 trajectory from the FIRST
+# step on -- equal to each other within 5 %.
+STEP1 = {('sgd', 'inception_v3'): (7e-2, 4.6e-2, 7e-2, 1e-5), ('sgd', 'resnet18'): (1.5e-2, 7.5e-3, 1.1e-2, 2e-7)}
 # Default sizes keep the GPU suite short (every HIP step costs an fp32 AND an fp64 oracle step on the host): inception_v3 at batch 8
-# for two steps, resnet18 at batch 16 for three.  IFCBK_FULL_TESTS=1 runs the configuration the numbers above were measured at
-# (batch 16, three steps, both optimizers in both storage types: 4.5 minutes).
+# for two steps, resnet18 at batch 16 for three -- in fp32 mode (SGD, Adam) AND in bf16 (SGD; round 5: inception_v3 too).
+# IFCBK_FULL_TESTS=1 adds nothing new in kind: batch 16, three steps, Adam for the bf16 twin as well (4.5 minutes).
 import os
 FULL = os.environ.get('IFCBK_FULL_TESTS', '0') != '0'
 CASES = [('inception_v3', 10, 16 if FULL else 8, 299, 3 if FULL else 2), ('resnet18', 2, 16, 224, 3)]
 
 
+def _ratios(tag, traj):
+    """the arbitrated ratios as one line per step (what GPUTEST_rNN shows): HIP-to-fp64 distance / oracle-to-fp64 distance"""
+    for k, t in enumerate(traj):
+        mo, wo = _med(t['arb_o']), max(t['arb_o'].values())
+        print('%s step %d: ARBITRATED ratio (HIP vs fp64) / (oracle vs fp64): median %.3f worst-tensor %.3f BN-buffers %.3f  [bound %.1f]'
+              % (tag, k + 1, _med(t['arb_h']) / max(mo, 1e-30), max(t['arb_h'].values()) / max(wo, 1e-30),
+                 t['barb_h'] / max(t['barb_o'], 1e-30), ARB))
+
+
 def _check(opt, name, traj, loss_tol):
-    uw, um, ww, bb = STEP1[(opt, name)]
     t = traj[0]
-    assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
+    if (opt, name) in STEP1:
+        uw, um, ww, bb = STEP1[(opt, name)]
+        assert t['upd'] < uw and t['upd_median'] < um and t['w'] < ww and t['buf'] < bb
     assert abs(t['loss_h'] - t['loss_o']) < 1e-4 * abs(t['loss_o'])          # same weights, same batch: measured 6e-7
     for t in traj:
         assert t['nbt_ok']
@@ -194,6 +207,7 @@ def _check(opt, name, traj, loss_tol):
 def test_fp32_trained_weights_sgd(name, nc, B, S, steps):
     traj = _trajectories(name, nc, B, S, 'fp32', 'sgd', steps=steps, arbiter=True)
     _report('fp32 SGD(0.005, m=0.9) ' + name, traj)
+    _ratios('fp32 SGD ' + name, traj)
     _check('sgd', name, traj, 4e-2)
 
 
@@ -201,16 +215,19 @@ def test_fp32_trained_weights_sgd(name, nc, B, S, steps):
 def test_fp32_trained_weights_adam(name, nc, B, S, steps):
     traj = _trajectories(name, nc, B, S, 'fp32', 'adam', steps=steps, arbiter=True)
     _report('fp32 Adam(1e-3) ' + name, traj)
+    _ratios('fp32 Adam ' + name, traj)
     _check('adam', name, traj, 4e-2)
 
 
-@pytest.mark.parametrize('name,nc,B,S,steps', CASES if FULL else CASES[1:])
+@pytest.mark.parametrize('name,nc,B,S,steps', CASES)
 def test_bf16_trained_weights_twin(name, nc, B, S, steps):
-    """the performance mode against the bf16-STORAGE oracle, arbitrated by the same fp64 trajectory: the HIP bf16 path must be as
-    close to it as the oracle's own bf16-storage arithmetic is -- its own (measured, printed) numbers, never quoted as the fp32 parity"""
+    """the performance mode -- the HEADLINE configuration's model and dtype: inception_v3 in bf16 runs by default --
+    against the bf16-STORAGE oracle, arbitrated by the same fp64 trajectory: the HIP bf16 path must be as close to it as the
+    oracle's own bf16-storage arithmetic is -- its own (measured, printed) numbers, never quoted as the fp32 parity"""
     for optimizer in (('sgd', 'adam') if FULL else ('sgd',)):
         traj = _trajectories(name, nc, B, S, 'bf16', optimizer, steps=steps if FULL else 2, arbiter=True)
         _report('bf16 %s %s' % (optimizer, name), traj)
+        _ratios('bf16 %s %s' % (optimizer, name), traj)
         for t in traj:
             assert t['nbt_ok']
             assert abs(t['loss_h'] - t['loss_o']) < 0.1 * abs(t['loss_o'])

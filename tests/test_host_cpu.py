@@ -96,6 +96,17 @@ def test_header_and_binding_export_the_same_symbols():
     assert 'IFCBK_OP_SGD' in hdr and _lib.OP_SGD == 30
 
 
+def test_the_dynamic_symbol_table_holds_the_c_abi_and_nothing_else():
+    """built with -fvisibility=hidden + a linker version script, the library exports exactly the entry points
+    include/ifcbk.h declares -- no C++-mangled internal launch helper, no compiler-generated object"""
+    import subprocess
+    from ifcb_classifier_amd import _lib
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ifcb_classifier_amd', 'libifcbk.so')
+    out = subprocess.run(['nm', '-D', '--defined-only', so], stdout=subprocess.PIPE, text=True, check=True).stdout
+    syms = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert syms == set(_lib.EXPORTS), syms ^ set(_lib.EXPORTS)
+
+
 def test_schema_v1_bins_are_refused_not_silently_unstitched(monkeypatch):
     """upstream classifies old-style bins through pyifcb's InfilledImages (neuston_data.py:446-449); raw halves would be a
     different ROI set, so the dataset refuses unless told otherwise"""

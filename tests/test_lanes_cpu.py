@@ -107,3 +107,38 @@ def test_weight_gradients_have_their_own_lane_and_wait_for_their_operands():
     # no two layers share a d(raw) buffer any more
     ptrs = [t.data_ptr() for t in eng.draw_own.values()]
     assert len(ptrs) == len(set(ptrs)) and len(ptrs) >= 60          # (the sibling GEMMs' members share their group's merged tensor)
+
+
+def test_plan_with_the_side_lane_switch_builds(monkeypatch):
+    """IFCBK_WGRAD_SIDE=1 (still documented in scripts/README.md) raised AttributeError in plan() -- the lane expression
+    read an attribute an earlier diff had removed"""
+    from ifcb_classifier_amd import graph, _lib
+    from ifcb_classifier_amd.engine import Engine
+    monkeypatch.setenv('IFCBK_WGRAD_SIDE', '1')
+    eng = Engine(graph.build('inception_v3', 7), max_batch=2, plan_only=True)
+    assert eng.wgrad_side_lane and eng.wgrad_lane == 0
+    pl = eng.plan(2)
+    ops, meta = pl.bwd_list.ops, pl.bwd_list.meta
+    sched = schedule_lanes(meta)
+    lanes = {sched[j][0] for j, o in enumerate(ops) if o.kind == _lib.OP_CONV_WGRAD}
+    assert len(lanes) > 1          # the weight gradients ride on their layers' NEIGHBOURING lanes, not on one lane of their own
+
+
+def test_program_lane_default_follows_the_job_size_not_the_construction_order(monkeypatch):
+    """an Engine built before init_process_group silently took the single-GPU lane count.  The world size now comes from
+    the argument or the launcher's WORLD_SIZE, and train_step_ddp refuses a world the lanes were not chosen for."""
+    import pytest
+    from ifcb_classifier_amd import graph
+    from ifcb_classifier_amd.engine import Engine
+    monkeypatch.delenv('IFCBK_LANES', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    net = graph.build('resnet18', 2)
+    assert Engine(net, max_batch=2, plan_only=True).NL == 4
+    assert Engine(net, max_batch=2, plan_only=True, dp_world=8).NL == 2
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    e = Engine(net, max_batch=2, plan_only=True)
+    assert e.NL == 2 and e.dp_world == 8 and e.wgrad_lane == 1
+    monkeypatch.delenv('WORLD_SIZE')
+    e1 = Engine(net, max_batch=2, plan_only=True)
+    with pytest.raises(RuntimeError, match='dp_world'):
+        e1.train_step_ddp(2, 8, lambda *a, **k: None)
