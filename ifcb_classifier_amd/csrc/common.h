@@ -172,6 +172,9 @@ int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* 
 // conv_flat.hip: flat-image kernel for stride-1 3x3 / 5x5 layers with 48..96 channels; returns its BatchNorm partial rows (= persistent grid; 0: not served)
 int ifcbk_conv_flat_rows(int dtype, int N, int H, int W, int cin, int kout, int R, int S, int ph, int pw, int P, int Q);
 int ifcbk_conv_flat_launch(ifcbk_ctx* ctx, void* conv_args, int N, hipStream_t st);
+// conv_slab.hip: pixel-slab kernel for stride-1 multi-tap layers (17x17 1x7 / 7x1 ...); plan returns the pixel tile / 32 (0: not served)
+int ifcbk_conv_slab_plan(int dtype, int N, int H, int W, int C, int K, int R, int S, int ph, int pw, int P, int Q);
+int ifcbk_conv_slab_launch(ifcbk_ctx* ctx, void* conv_args, int N, hipStream_t st);
 int ifcbk_conv_fwd_nt(int K, int M);
 bool ifcbk_conv_ws_shape(int dtype, int M, int K, int Kg);     // the persistent warp-specialised kernel serves this GEMM shape
 int ifcbk_conv_fwd_wm(int M, int K);

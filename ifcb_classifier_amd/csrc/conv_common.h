@@ -40,6 +40,10 @@ struct ConvArgs {
     int wKg, wSfull, w_rbase, w_sbase;      // filter row length (elements), full S, first tap row / column (step 2)
     int oH, oW, o_a, o_b;                   // dx dims and the class parity: output pixel (n,i,j) -> (n, 2i+o_a, 2j+o_b)
     fastdiv_t fPQ, fQ;
+    // conv_slab.hip, column-major tiles (7x1 filters): tile row m counts the output pixels in (n, q, p) order; its NHWC row is
+    // n * PQ + p * Q + q
+    int tr;
+    fastdiv_t fP;
     int dbg;                                // timing-only diagnostics of conv_big.hip (0 in production)
 };
 
@@ -176,6 +180,13 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     const int r = r0 + (b + u) * RPP;
                     const int m = (RT % UB == 0 || b + u < RT) ? m0 + r : a.M;      // rows past the tile (RT not a multiple of UB)
                     opx[u] = (size_t)m;
+                    if (MODE != 2 && a.tr && m < a.M) {
+                        const uint32_t on = fdiv((uint32_t)m, a.fPQ);
+                        const uint32_t orem = (uint32_t)m - on * a.fPQ.d;
+                        const uint32_t oq = fdiv(orem, a.fP);
+                        const uint32_t op = orem - oq * a.fP.d;
+                        opx[u] = (size_t)on * a.fPQ.d + (size_t)op * a.Q + oq;
+                    }
                     if (MODE == 2 && m < a.M) {
                         const uint32_t on = fdiv((uint32_t)m, a.fPQ);
                         const uint32_t orem = (uint32_t)m - on * a.fPQ.d;
@@ -185,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     }
                     if (m < a.M) {
                         if (a.accumulate) pre[u] = Chunk<T>::load_raw((const T*)a.y + opx[u] * a.ldy + nn);
-                        if (a.ep_scale && a.ep_res) prer[u] = Chunk<T>::load_raw((const T*)a.ep_res + (size_t)m * a.ep_ldr + nn);
+                        if (a.ep_scale && a.ep_res) prer[u] = Chunk<T>::load_raw((const T*)a.ep_res + (MODE == 2 ? (size_t)m : opx[u]) * a.ep_ldr + nn);
                         if (BTAB) {
                             if (braw) prb[u] = Chunk<T>::load_raw(braw + opx[u] * bld);
                         } else if (BSTAT) {

@@ -573,6 +573,12 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
         if (ifcbk_conv_flat_rows(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
             return ifcbk_conv_flat_launch(ctx, &a, N, st);
     }
+    // stride-1 multi-tap layers of the 17x17 class: the pixel-slab kernel (conv_slab.hip); every epilogue but the table / segment forms
+    if (big_ok(a) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && a.PQ > 0) {
+        const int N = a.M / a.PQ;
+        if (ifcbk_conv_slab_plan(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
+            return ifcbk_conv_slab_launch(ctx, &a, N, st);
+    }
     // grids of several tiles per CU whose epilogue is a raw store (+ statistics) or the eval affine: the persistent kernel
     if (pp3_ok(a) && ifcbk_conv_pp3_plan(dtype, a.M, a.K, a.Kg, a.ep_scale ? 1 : 0)) return ifcbk_conv_pp3_launch(ctx, &a, st);
     {
@@ -643,6 +649,8 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
     int M = d->N * d->P * d->Q;
     if (d->stride_h == 1 && d->stride_w == 1)
         if (int fs = ifcbk_conv_flat_rows(d->dtype, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->pad_h, d->pad_w, d->P, d->Q)) return fs;
+    if (d->stride_h == 1 && d->stride_w == 1)
+        if (int smt = ifcbk_conv_slab_plan(d->dtype, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->pad_h, d->pad_w, d->P, d->Q)) return cdiv(M, 32 * smt);
     if (ifcbk_conv_pp3_plan(d->dtype, M, d->K, d->R * d->S * d->C, 0)) return 2 * cdiv(M, 256);      // conv_pp3: one partial row per pixel half
     {
         int bmt = 0, btn = 0;
@@ -758,7 +766,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
         return ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,
                                       bn_part, scale, shift, relu, (hipStream_t)stream);
     ConvArgs a;
-    a.dbg = 0;
+    a.dbg = 0; a.tr = 0; a.fP = make_fastdiv(1);
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
     a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0; a.bs_tab = nullptr;
@@ -806,6 +814,7 @@ extern "C" int ifcbk_conv2d_dgrad_bnstat_mblocks(const ifcbk_conv_desc* d) {
     if (!d || !dgrad_bnstat_ok(d)) return 0;
     int M = d->N * d->H * d->W;
     if (int fs = ifcbk_conv_flat_rows(d->dtype, d->N, d->P, d->Q, d->K, d->C, d->R, d->S, d->R - 1 - d->pad_h, d->S - 1 - d->pad_w, d->H, d->W)) return fs;
+    if (int smt = ifcbk_conv_slab_plan(d->dtype, d->N, d->P, d->Q, d->K, d->C, d->R, d->S, d->R - 1 - d->pad_h, d->S - 1 - d->pad_w, d->H, d->W)) return cdiv(M, 32 * smt);
     {
         int bmt = 0, btn = 0;
         if (ifcbk_conv_big_plan(d->dtype, M, d->C, d->R * d->S * d->K, &bmt, &btn)) return cdiv(M, 32 * bmt);
@@ -841,7 +850,7 @@ static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, 
                                       wT, dx, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
-    a.dbg = 0;
+    a.dbg = 0; a.tr = 0; a.fP = make_fastdiv(1);
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
     a.x = dy; a.w = wT; a.y = dx; a.part = bs ? bs->part : nullptr;
     a.seg_n = 0;

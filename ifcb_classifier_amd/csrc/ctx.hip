@@ -507,6 +507,12 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 snprintf(name, cap, "conv_flat<%d, %d, %d, %d, 0>", d.C, d.K, d.R, d.S);
                 break;
             }
+            if (!rows && d.stride_h == 1 && d.stride_w == 1) {
+                if (const int smt = ifcbk_conv_slab_plan(d.dtype, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.pad_h, d.pad_w, d.P, d.Q)) {
+                    snprintf(name, cap, "conv_slab<%d, %d, %d, %d, 50, 0>", d.K <= 128 ? 2 : 3, smt, smt == 10 ? 4 : smt / 2, d.R * d.S);
+                    break;
+                }
+            }
             if (!rows && !(o->kind == IFCBK_OP_CONV_FWD_AFFINE && o->p[5]) &&
                 ifcbk_conv_pp3_plan(d.dtype, d.N * d.P * d.Q, d.K, d.R * d.S * d.C, o->kind == IFCBK_OP_CONV_FWD_AFFINE ? 1 : 0)) {
                 ifcbk_conv_pp3_name(d.R * d.S * d.C, o->kind == IFCBK_OP_CONV_FWD_AFFINE,
@@ -538,6 +544,13 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                     ifcbk_conv_flat_rows(d.dtype, d.N, d.P, d.Q, d.K, d.C, d.R, d.S, d.R - 1 - d.pad_h, d.S - 1 - d.pad_w, d.H, d.W)) {
                     snprintf(name, cap, "conv_flat<%d, %d, %d, %d, %d>", d.K, d.C, d.R, d.S, o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
                     break;
+                }
+                if (!s2 && o->kind != IFCBK_OP_CONV_DGRAD_BNSTAT_TAB) {
+                    if (const int smt = ifcbk_conv_slab_plan(d.dtype, d.N, d.P, d.Q, d.K, d.C, d.R, d.S, d.R - 1 - d.pad_h, d.S - 1 - d.pad_w, d.H, d.W)) {
+                        snprintf(name, cap, "conv_slab<%d, %d, %d, %d, 50, %d>", d.C <= 128 ? 2 : 3, smt, smt == 10 ? 4 : smt / 2, d.R * d.S,
+                                 o->kind == IFCBK_OP_CONV_DGRAD_BNSTAT ? 3 : 0);
+                        break;
+                    }
                 }
                 int bmt = 0, btn = 0;
                 if (!s2 && o->kind == IFCBK_OP_CONV_DGRAD && !(o->flags & 1) && ifcbk_conv_pp3_plan(d.dtype, d.N * d.H * d.W, d.C, d.R * d.S * d.K, 0)) {

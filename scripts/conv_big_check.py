@@ -1,7 +1,8 @@
 """dev tool: the wide-tile ping-pong kernel (conv_big) against conv_igemm / conv_ws on the inception_v3 layer shapes at batch
 256, in ONE process (IFCBK_CONV_BIG is read per launch): correctness of forward (+ BatchNorm partial sums) and input gradient
 against torch's fp32 GPU convolution of the same bf16 operands, then interleaved timing rounds.
-    python scripts/conv_big_check.py [layers|all] [reps]"""
+    python scripts/conv_big_check.py [layers|all] [reps]
+CHECK_SWITCH=IFCBK_CONV_SLAB compares the pixel-slab kernel (conv_slab.hip) with what the dispatcher picks without it."""
 import ctypes as C
 import os
 import sys
@@ -22,6 +23,8 @@ LAYERS = {
     '6c_7x1o':   (256, 160, 17, 17, 192, 7, 1, 1, 1, 3, 0),
     '6e_7x1':    (256, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0),
     '6e_1x7':    (256, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3),
+    '6c_7x1':    (256, 160, 17, 17, 160, 7, 1, 1, 1, 3, 0),
+    '6b_7x1':    (256, 128, 17, 17, 128, 7, 1, 1, 1, 3, 0),
     '6b_1x1g':   (256, 768, 17, 17, 640, 1, 1, 1, 1, 0, 0),
     '6e_1x1g':   (256, 768, 17, 17, 768, 1, 1, 1, 1, 0, 0),
     '7a_1x1g':   (256, 768, 17, 17, 384, 1, 1, 1, 1, 0, 0),
@@ -35,6 +38,7 @@ LAYERS = {
 which = sys.argv[1].split(',') if len(sys.argv) > 1 and sys.argv[1] != 'all' else list(LAYERS)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 NOVR = int(os.environ.get('CONV_LAYERS_N', '0'))
+SW = os.environ.get('CHECK_SWITCH', 'IFCBK_CONV_BIG')
 ctx = _lib.Context(0)
 ctx.reserve(1 << 30)
 st = _lib.cur_stream()
@@ -76,7 +80,7 @@ for name in which:
     for mode in modes:
         outs = {}
         for big in ('0', '1'):
-            os.environ['IFCBK_CONV_BIG'] = big
+            os.environ[SW] = big
             kn = kname(d, _lib.OP_CONV_FWD if mode == 'fwd' else _lib.OP_CONV_DGRAD)
             if mode == 'fwd':
                 y = torch.full((N, P, Q, K), float('nan'), device='cuda', dtype=torch.bfloat16)
@@ -97,7 +101,7 @@ for name in which:
         ms = {'0': [], '1': []}
         for r in range(reps):
             for big in ('0', '1'):
-                os.environ['IFCBK_CONV_BIG'] = big
+                os.environ[SW] = big
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):

@@ -21,3 +21,15 @@ def ctx():
     c = _lib.Context(0)
     c.reserve(512 << 20)
     return c
+
+
+# Measured figures that must be visible in a GREEN log (`pytest -q` shows the output of failing tests only): a test appends lines to
+# MEASURED (tests/local_parity.py: measured(...)) and they are printed after the run, under the pass / fail summary line's section.
+MEASURED = []
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if MEASURED:
+        terminalreporter.section('measured (printed by passing tests)')
+        for ln in MEASURED:
+            terminalreporter.write_line(ln)

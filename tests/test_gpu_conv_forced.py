@@ -41,7 +41,7 @@ def _kname(ctx, d, kind, flags=0, residual=False):
 def forced(monkeypatch):
     def set_(**kw):
         for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
-                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID'):
+                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_CONV_SLAB'):
             monkeypatch.delenv(k, raising=False)
         for k, v in kw.items():
             monkeypatch.setenv(k, str(v))
@@ -91,11 +91,45 @@ WIDE = [
 
 @pytest.mark.parametrize('case,mt,tn,lx,ly', WIDE)
 def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, lx, ly):
-    from ifcb_classifier_amd import _lib
-    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)      # (conv_pp3 has its own test below)
+    env = dict(IFCBK_CONV_BIG=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0, IFCBK_CONV_SLAB=0)      # (conv_pp3 / conv_slab have their own tests below)
     if mt:
         env.update(IFCBK_CONV_BIG_MT=mt, IFCBK_CONV_BIG_TN=tn)
     forced(**env)
+    _check_forward_and_input_gradient(ctx, case, lx, ly, 'conv_pp2<')
+
+
+# the pixel-slab kernel (conv_slab.hip, round 5): 7-tap filters along either axis (row-major 1x7, column-major 7x1 tiles), M tails
+# (867 = 2.7 tiles of 320; 578 = 1.8), channel chunks with a tail (160 = 64 + 64 + 32, 72 = 64 + 8), both column tiles (128 / 192),
+# K tails (136 of 192, 104 of 128), channel slices of wider tensors, lines shorter and longer than inception's 17
+SLAB = [
+    ((3, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3), 0, 0),         # inception's own 1x7 on an M tail
+    ((3, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), 0, 0),         # ... and its 7x1: column-major tiles, transposed epilogue
+    ((2, 160, 17, 17, 136, 7, 1, 1, 1, 3, 0), 16, 24),       # chunk tail (32 of 64), K tail, slices
+    ((2, 128, 17, 17, 128, 1, 7, 1, 1, 0, 3), 8, 0),         # the 128-channel column tile
+    ((4, 72, 12, 23, 104, 1, 7, 1, 1, 0, 3), 0, 8),          # 8-channel chunk tail, long lines, K tail of the 128-wide tile
+    ((5, 64, 21, 11, 192, 7, 1, 1, 1, 3, 0), 0, 0),          # one chunk; column-major with 21-pixel lines
+]
+
+
+@pytest.mark.parametrize('case,lx,ly', SLAB)
+def test_pixel_slab_kernel_forced(ctx, forced, case, lx, ly):
+    forced(IFCBK_CONV_SLAB=2, IFCBK_CONV_BIG=0, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)
+    _check_forward_and_input_gradient(ctx, case, lx, ly, 'conv_slab<')
+
+
+def test_pixel_slab_kernel_declines_what_its_slab_cannot_hold(ctx, forced):
+    """a 1x7 filter over 9-pixel lines: 320 pixels touch 37 lines, 438 slab rows > the 400 of the instantiation -- the plan must say
+    no (and the implicit GEMM serves the layer), never launch with a slab that is too short"""
+    from ifcb_classifier_amd import _lib
+    forced(IFCBK_CONV_SLAB=2, IFCBK_CONV_BIG=0, IFCBK_CONV_FLAT=0, IFCBK_CONV_PP3=0)
+    case = (8, 64, 9, 9, 192, 1, 7, 1, 1, 0, 3)
+    d = _desc(case, 9, 9, 64, 192)
+    assert not _kname(ctx, d, _lib.OP_CONV_FWD).startswith('conv_slab<')
+    _check_forward_and_input_gradient(ctx, case, 0, 0, 'conv_')
+
+
+def _check_forward_and_input_gradient(ctx, case, lx, ly, prefix):
+    from ifcb_classifier_amd import _lib
     N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
     x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 11, lx, ly)
     d = _desc(case, P, Q, LDX, LDY)
@@ -106,7 +140,7 @@ def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, 
     yref = yr.detach().permute(0, 2, 3, 1)
     xp, _ = _slice(xb, lx // 2, Cc)
     # ---- forward + BatchNorm partial sums (MODE 0)
-    assert _kname(ctx, d, _lib.OP_CONV_FWD).startswith('conv_pp2<'), _kname(ctx, d, _lib.OP_CONV_FWD)
+    assert _kname(ctx, d, _lib.OP_CONV_FWD).startswith(prefix), _kname(ctx, d, _lib.OP_CONV_FWD)
     yb = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
     yp, yv = _slice(yb, ly // 2, K)
     mb = ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
@@ -133,7 +167,7 @@ def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, 
     if sh != 1:
         return
     # ---- input gradient: first writer, accumulating, with the BN-backward sums of one producer (MODE 3)
-    assert _kname(ctx, d, _lib.OP_CONV_DGRAD).startswith('conv_pp2<')
+    assert _kname(ctx, d, _lib.OP_CONV_DGRAD).startswith(prefix), _kname(ctx, d, _lib.OP_CONV_DGRAD)
     dyp, _ = _slice(dyb, ly // 2, K)
     dxb = torch.full((N, H, W, LDX), float('nan'), dtype=torch.bfloat16, device='cuda')
     dxp, dxv = _slice(dxb, lx // 2, Cc)
@@ -145,7 +179,7 @@ def test_wide_tile_forward_and_input_gradient_forced(ctx, forced, case, mt, tn, 
     ctx.call('ifcbk_conv2d_dgrad', C.byref(d), dyp, _lib.ptr(wT), dxp, 1, st)
     torch.cuda.synchronize()
     assert _rel(dxv.float().cpu(), 2 * first) < 6e-3
-    assert _kname(ctx, d, _lib.OP_CONV_DGRAD_BNSTAT).startswith('conv_pp2<') and _kname(ctx, d, _lib.OP_CONV_DGRAD_BNSTAT).endswith(', 3>')
+    assert _kname(ctx, d, _lib.OP_CONV_DGRAD_BNSTAT).startswith(prefix) and _kname(ctx, d, _lib.OP_CONV_DGRAD_BNSTAT).endswith(', 3>')
     raw = _bf(torch.randn(N, H, W, Cc, generator=g) * 1.5)
     mean, invstd = torch.randn(Cc, generator=g) * 0.2, torch.rand(Cc, generator=g) + 0.5
     bsc, bsh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3

@@ -183,11 +183,15 @@ CASES = [('inception_v3', 10, 16 if FULL else 8, 299, 3 if FULL else 2), ('resne
 
 def _ratios(tag, traj):
     """the arbitrated ratios as one line per step (what GPUTEST_rNN shows): HIP-to-fp64 distance / oracle-to-fp64 distance"""
+    import conftest
     for k, t in enumerate(traj):
         mo, wo = _med(t['arb_o']), max(t['arb_o'].values())
-        print('%s step %d: ARBITRATED ratio (HIP vs fp64) / (oracle vs fp64): median %.3f worst-tensor %.3f BN-buffers %.3f  [bound %.1f]'
-              % (tag, k + 1, _med(t['arb_h']) / max(mo, 1e-30), max(t['arb_h'].values()) / max(wo, 1e-30),
-                 t['barb_h'] / max(t['barb_o'], 1e-30), ARB))
+        ln = ('trained weights, %s step %d: update distance to the fp64 trajectory, HIP %.3e / oracle %.3e (median over tensors), ratio %.3f; '
+              'worst tensor ratio %.3f; BN buffers ratio %.3f [bound %.1f]; loss hip %.6f oracle %.6f'
+              % (tag, k + 1, _med(t['arb_h']), mo, _med(t['arb_h']) / max(mo, 1e-30), max(t['arb_h'].values()) / max(wo, 1e-30),
+                 t['barb_h'] / max(t['barb_o'], 1e-30), ARB, t['loss_h'], t['loss_o']))
+        print(ln)
+        conftest.MEASURED.append(ln)
 
 
 def _check(opt, name, traj, loss_tol):
