@@ -49,7 +49,7 @@ struct SlabArgs {
     int TB;                      // filter taps along the minor axis (filter order is (r, s): tap t = r * S + s)
     int tr;                      // 1: column-major
     int N;
-    fastdiv_t fImg, fLine, fOPQ, fOB;
+    fastdiv_t fImg, fLine, fOPQ, fOB, fTB;
 };
 
 // SLABP: LDS-DMA pieces (8 rows of 128 B) of one slab; wave w requests pieces w, w + 8, ...
@@ -123,26 +123,35 @@ __global__ __launch_bounds__(512) void conv_slab(ConvArgs a, SlabArgs s) {
     }
     const int ncc = (a.C + BK - 1) / BK;
     const int cclim = (a.C - csrc * CE + BK - 1) / BK;      // chunks cc < cclim hold this lane's 8 channels
-    const int nk = ncc * TAPS;
+    // A last chunk of at most 32 channels (160 = 64 + 64 + 32) takes its taps in PAIRS: K-tile u of that chunk multiplies tap 2u in its
+    // first 32 k and tap 2u + 1 in its second -- (TAPS + 1) / 2 K-tiles instead of TAPS half-empty ones
+    constexpr int TAPSH = (TAPS + 1) / 2;
+    const int tw = a.C - (ncc - 1) * BK;                    // channels of the last chunk (1..64)
+    const bool tailpair = tw <= 32;
+    const int nfull = tailpair ? ncc - 1 : ncc;             // chunks of TAPS K-tiles
+    const int nk = nfull * TAPS + (tailpair ? TAPSH : 0);
+    const bool pvalid = (csrc & 3) * CE < tw;               // paired K-tiles: this lane's 8 channels exist in the tail chunk
+    const unsigned padd = (unsigned)((csrc >> 2) * (a.C * ES - 64));      // ... and chunks 4-7 fetch the NEXT tap's chunks 0-3
     unsigned woff[TN];
 #pragma unroll
     for (int p = 0; p < TN; ++p) {
         const int n = n0 + p * 64 + wave * 8 + lrow8;
         woff[p] = n < a.K ? (unsigned)(n * a.Kg + csrc * CE) * (unsigned)ES : OOB;
     }
-
     // slab piece j of chunk CC into buffer CC & 1 (the caller has checked that this wave has a piece j: wave + 8 j < SLABP)
 #define SLAB_ISSUE_PIECE(J, CC)                                                                                           \
     {                                                                                                                     \
         unsigned char* dst = smem + ((CC) & 1) * SLAB_BYTES + (wave + 8 * (J)) * 1024;                                    \
         lds_dma16(rsA, (lptr_t)dst, (CC) < cclim ? slabva[J] : OOB, (CC) * 128);                                          \
     }
-    // filter tile of K-tile (CC, TT) into buffer KT & 1
-#define SLAB_ISSUE_B(KT, CC, TT)                                                                                          \
+    // filter tile of K-tile KT (chunk CC, first tap TT, paired?) into buffer KT & 1
+#define SLAB_ISSUE_B(KT, CC, TT, PAIR)                                                                                    \
     {                                                                                                                     \
+        const bool lv = (KT) < nk && ((PAIR) ? (pvalid && (csrc < 4 || (TT) + 1 < TAPS)) : (CC) < cclim);                 \
         _Pragma("unroll") for (int p = 0; p < TN; ++p) {                                                                  \
             unsigned char* dst = sFilt + ((KT) & 1) * BBUF + (p * 64 + wave * 8) * ROWB;                                  \
-            lds_dma16(rsB, (lptr_t)dst, ((KT) < nk && (CC) < cclim) ? woff[p] : OOB, ((TT) * a.C + (CC) * BK) * ES);      \
+            const unsigned vo = (PAIR) ? woff[p] + padd : woff[p];                                                        \
+            lds_dma16(rsB, (lptr_t)dst, (lv && woff[p] != OOB) ? vo : OOB, ((TT) * a.C + (CC) * BK) * ES);                \
         }                                                                                                                 \
     }
     // prologue: the slab of chunk 0 and the filter tile of K-tile 0
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_slab(ConvArgs a, SlabArgs s) {
 #pragma unroll
     for (int j = 0; j < SPW; ++j)
         if (j < npw) SLAB_ISSUE_PIECE(j, 0)
-    SLAB_ISSUE_B(0, 0, 0)
+    SLAB_ISSUE_B(0, 0, 0, nfull == 0)
 
     unsigned faB[2];
 #pragma unroll
@@ -177,105 +186,122 @@ __global__ __launch_bounds__(512) void conv_slab(ConvArgs a, SlabArgs s) {
 #pragma unroll
     for (int i = 0; i < PMX; ++i) fa[i][0] = fa[i][1] = bf16x8_t{};
 
-    // fragment pair of pixel tile ML at slab row rowbase + shift: chunk (kk * 4 + fchunk) ^ (row & 7) of the row
-#define SLAB_READ_A(DST, ML, SHIFT, SBASE)                                                                                \
+    // fragment pair of pixel tile ML at slab row rowbase + SHA: chunk (kk * 4 + fchunk) ^ (row & 7) of the row; PAIRC (compile-time):
+    // the second 32 k are chunks 0-3 of row rowbase + SHB (the next tap of a paired K-tile) instead of chunks 4-7 of the same row
+#define SLAB_READ_A(PAIRC, DST, ML, SHA, SHB, SBASE)                                                                      \
     {                                                                                                                     \
-        const int row = rowbase[ML] + (SHIFT);                                                                            \
-        const unsigned ad = (SBASE) + (unsigned)(row * ROWB) + (unsigned)(((fchunk ^ row) & 7) << 4);                     \
-        SLAB_DSREAD(fa[DST][0], ad);                                                                                      \
-        SLAB_DSREAD(fa[DST][1], ad ^ 64u);                                                                                \
+        const int rowA = rowbase[ML] + (SHA);                                                                             \
+        const unsigned adA = (SBASE) + (unsigned)(rowA * ROWB) + (unsigned)(((fchunk ^ rowA) & 7) << 4);                  \
+        SLAB_DSREAD(fa[DST][0], adA);                                                                                     \
+        if (PAIRC) {                                                                                                      \
+            const int rowB = rowbase[ML] + (SHB);                                                                         \
+            const unsigned adB = (SBASE) + (unsigned)(rowB * ROWB) + (unsigned)(((fchunk ^ rowB) & 7) << 4);              \
+            SLAB_DSREAD(fa[DST][1], adB);                                                                                 \
+        } else {                                                                                                          \
+            SLAB_DSREAD(fa[DST][1], adA ^ 64u);                                                                           \
+        }                                                                                                                 \
+    }
+    // One K-tile (both phases).  U: its index inside its chunk, LASTU: the chunk's last, MORE: a next chunk exists (its slab is
+    // requested during this one), CCN: that chunk; NKT / NCC / NTT / NPAIR: the NEXT K-tile, whose filter tile is requested here
+#define SLAB_KTILE(PAIRC, PARQ, SHA, SHB, SBASE, U, LASTU, MORE, CCN, NKT, NCC, NTT, NPAIR)                               \
+    {                                                                                                                     \
+        /* ================================================ even phase */                                                 \
+        {                                                                                                                 \
+            const unsigned bB0 = faB[0] + (PARQ) * BBUF, bB1 = faB[1] + (PARQ) * BBUF;                                    \
+            _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) {                                                           \
+                if (nt == 0) { SLAB_DSREAD_OFF(fb[0][0], bB0, 0); SLAB_DSREAD_OFF(fb[0][1], bB1, 0); }                    \
+                if (nt == 1) { SLAB_DSREAD_OFF(fb[1][0], bB0, 16 * ROWB); SLAB_DSREAD_OFF(fb[1][1], bB1, 16 * ROWB); }    \
+                if (nt == 2) { SLAB_DSREAD_OFF(fb[2][0], bB0, 32 * ROWB); SLAB_DSREAD_OFF(fb[2][1], bB1, 32 * ROWB); }    \
+                if (nt == 3) { SLAB_DSREAD_OFF(fb[3][0], bB0, 48 * ROWB); SLAB_DSREAD_OFF(fb[3][1], bB1, 48 * ROWB); }    \
+            }                                                                                                             \
+            _Pragma("unroll") for (int ml = 0; ml < PM0; ++ml) SLAB_READ_A(PAIRC, ml, ml, SHA, SHB, SBASE)                \
+            SLAB_ISSUE_B(NKT, NCC, NTT, NPAIR)                                                                            \
+            /* slab piece 2U - 1 of the next chunk (even phases of K-tiles 1 .. of a chunk) */                            \
+            if ((MORE) && (U) >= 1 && 2 * (U) - 1 < npw) {                                                                \
+                _Pragma("unroll") for (int j = 0; j < SPW; ++j)                                                           \
+                    if (j == 2 * (U) - 1) SLAB_ISSUE_PIECE(j, CCN)                                                        \
+            }                                                                                                             \
+            /* (nothing this K-tile reads is still in flight: its filter tile was waited for in the previous odd phase, its  \
+               slab a chunk ago) */                                                                                       \
+            __builtin_amdgcn_s_barrier();                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) asm volatile("" : "+v"(fb[nt][0]), "+v"(fb[nt][1]));        \
+            _Pragma("unroll") for (int ml = 0; ml < PM0; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));       \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            __builtin_amdgcn_s_setprio(1);                                                                                \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+                _Pragma("unroll") for (int ml = 0; ml < PM0; ++ml)                                                        \
+                    _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                     \
+                        acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[ml][nt], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                 \
+            asm volatile("" ::: "memory");                                                                                \
+        }                                                                                                                 \
+        /* ================================================ odd phase */                                                  \
+        {                                                                                                                 \
+            _Pragma("unroll") for (int ml = 0; ml < PM1; ++ml) SLAB_READ_A(PAIRC, ml, PM0 + ml, SHA, SHB, SBASE)          \
+            /* slab piece 2U of the next chunk (odd phases of K-tiles 0 .. of a chunk, not its last), then: the filter tile \
+               of the next K-tile has landed once at most the slab pieces requested behind it are outstanding */          \
+            const bool so = (MORE) && 2 * (U) < npw && !(LASTU);                                                          \
+            const bool se = (MORE) && (U) >= 1 && 2 * (U) - 1 < npw;                                                      \
+            if (so) {                                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < SPW; ++j)                                                           \
+                    if (j == 2 * (U)) SLAB_ISSUE_PIECE(j, CCN)                                                            \
+            }                                                                                                             \
+            if (LASTU) wait_vmcnt<0>();                     /* ... and the next chunk's slab, whole */                    \
+            else if (so && se) wait_vmcnt<2>();                                                                           \
+            else if (so || se) wait_vmcnt<1>();                                                                           \
+            else wait_vmcnt<0>();                                                                                         \
+            __builtin_amdgcn_s_barrier();                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+            _Pragma("unroll") for (int ml = 0; ml < PM1; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));       \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            __builtin_amdgcn_s_setprio(1);                                                                                \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                              \
+                _Pragma("unroll") for (int ml = 0; ml < PM1; ++ml)                                                        \
+                    _Pragma("unroll") for (int nt = 0; nt < TN; ++nt)                                                     \
+                        acc[PM0 + ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[PM0 + ml][nt], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                 \
+            asm volatile("" ::: "memory");                                                                                \
+        }                                                                                                                 \
     }
 
     int kt = 0;
-    for (int cc = 0; cc < ncc; ++cc) {
+    // ---- chunks of TAPS K-tiles: tap t = (ta, tb) along (major, minor), filter order (r, s)
+    for (int cc = 0; cc < nfull; ++cc) {
         const unsigned sbase = slab0 + (unsigned)((cc & 1) * SLAB_BYTES);
-        int ta = 0, tb = 0;                                // tap t = (ta, tb) along (major, minor); filter order is (r, s)
+        const bool more = cc + 1 < ncc;
+        int ta = 0, tb = 0;
 #pragma unroll 1
         for (int tt = 0; tt < TAPS; ++tt, ++kt) {
             const unsigned par = (unsigned)(kt & 1);
             const int shift = ta * s.MinP + tb;
             const bool lastt = tt == TAPS - 1;
-            // the NEXT K-tile (its filter tile is requested in this K-tile's even phase)
             const int ncc_ = lastt ? cc + 1 : cc, ntt_ = lastt ? 0 : tt + 1;
-            // ================================================ even phase
-            {
-                const unsigned bB0 = faB[0] + par * BBUF, bB1 = faB[1] + par * BBUF;
-#pragma unroll
-                for (int nt = 0; nt < TN; ++nt) {
-                    if (nt == 0) { SLAB_DSREAD_OFF(fb[0][0], bB0, 0); SLAB_DSREAD_OFF(fb[0][1], bB1, 0); }
-                    if (nt == 1) { SLAB_DSREAD_OFF(fb[1][0], bB0, 16 * ROWB); SLAB_DSREAD_OFF(fb[1][1], bB1, 16 * ROWB); }
-                    if (nt == 2) { SLAB_DSREAD_OFF(fb[2][0], bB0, 32 * ROWB); SLAB_DSREAD_OFF(fb[2][1], bB1, 32 * ROWB); }
-                    if (nt == 3) { SLAB_DSREAD_OFF(fb[3][0], bB0, 48 * ROWB); SLAB_DSREAD_OFF(fb[3][1], bB1, 48 * ROWB); }
-                }
-#pragma unroll
-                for (int ml = 0; ml < PM0; ++ml) SLAB_READ_A(ml, ml, shift, sbase)
-                SLAB_ISSUE_B(kt + 1, ncc_, ntt_)
-                // slab piece 2 * tt - 1 of the next chunk (even phases of taps 1 ..)
-                if (tt >= 1 && 2 * tt - 1 < npw && cc + 1 < ncc) {
-#pragma unroll
-                    for (int j = 0; j < SPW; ++j)
-                        if (j == 2 * tt - 1) SLAB_ISSUE_PIECE(j, cc + 1)
-                }
-                // (nothing this K-tile reads is still in flight: its filter tile was waited for in the previous odd phase, its slab
-                // a chunk ago)
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int nt = 0; nt < TN; ++nt) asm volatile("" : "+v"(fb[nt][0]), "+v"(fb[nt][1]));
-#pragma unroll
-                for (int ml = 0; ml < PM0; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int ml = 0; ml < PM0; ++ml)
-#pragma unroll
-                        for (int nt = 0; nt < TN; ++nt)
-                            acc[ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[ml][nt], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-            // ================================================ odd phase
-            {
-#pragma unroll
-                for (int ml = 0; ml < PM1; ++ml) SLAB_READ_A(ml, PM0 + ml, shift, sbase)
-                // slab piece 2 * tt of the next chunk (odd phases of taps 0 ..), then: the filter tile of the next K-tile has landed
-                // once at most the slab pieces requested behind it are outstanding (this phase's and the even phase's)
-                const bool so = 2 * tt < npw && !lastt && cc + 1 < ncc;
-                const bool se = tt >= 1 && 2 * tt - 1 < npw && cc + 1 < ncc;
-                if (so) {
-#pragma unroll
-                    for (int j = 0; j < SPW; ++j)
-                        if (j == 2 * tt) SLAB_ISSUE_PIECE(j, cc + 1)
-                }
-                if (lastt) wait_vmcnt<0>();                 // ... and the next chunk's slab, whole
-                else if (so && se) wait_vmcnt<2>();
-                else if (so || se) wait_vmcnt<1>();
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int ml = 0; ml < PM1; ++ml) asm volatile("" : "+v"(fa[ml][0]), "+v"(fa[ml][1]));
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int ml = 0; ml < PM1; ++ml)
-#pragma unroll
-                        for (int nt = 0; nt < TN; ++nt)
-                            acc[PM0 + ml][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt][kk], fa[ml][kk], acc[PM0 + ml][nt], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
+            const bool npair_ = lastt && cc + 1 == nfull;          // (only reached with a paired tail: otherwise kt + 1 == nk and the tile is dropped)
+            SLAB_KTILE(false, par, shift, shift, sbase, tt, lastt, more, cc + 1, kt + 1, ncc_, ntt_, npair_)
             if (++tb == s.TB) { tb = 0; ++ta; }
         }
     }
+    // ---- a last chunk of <= 32 channels: two taps per K-tile
+    if (tailpair) {
+        const int cc = ncc - 1;
+        const unsigned sbase = slab0 + (unsigned)((cc & 1) * SLAB_BYTES);
+        int ta = 0, tb = 0;
+#pragma unroll 1
+        for (int u = 0; u < TAPSH; ++u, ++kt) {
+            const unsigned par = (unsigned)(kt & 1);
+            const int shA = ta * s.MinP + tb;
+            if (++tb == s.TB) { tb = 0; ++ta; }
+            const int shB = 2 * u + 1 < TAPS ? ta * s.MinP + tb : shA;     // (an absent second tap: its filter half is zero, any finite pixels do)
+            if (++tb == s.TB) { tb = 0; ++ta; }
+            SLAB_KTILE(true, par, shA, shB, sbase, u, u == TAPSH - 1, false, cc, kt + 1, cc, 2 * u + 2, true)
+        }
+    }
+#undef SLAB_KTILE
 #undef SLAB_ISSUE_PIECE
 #undef SLAB_ISSUE_B
 #undef SLAB_READ_A
@@ -387,7 +413,7 @@ int ifcbk_conv_slab_launch(ifcbk_ctx* ctx, void* args, int N, hipStream_t st) {
     s.simg = a.H * a.W * a.ldx;
     s.TB = g.TB; s.tr = g.tr; s.N = N;
     s.fImg = make_fastdiv((uint32_t)s.ImgP); s.fLine = make_fastdiv((uint32_t)s.MinP);
-    s.fOPQ = make_fastdiv((uint32_t)(g.OA * g.OB)); s.fOB = make_fastdiv((uint32_t)g.OB);
+    s.fOPQ = make_fastdiv((uint32_t)(g.OA * g.OB)); s.fOB = make_fastdiv((uint32_t)g.OB); s.fTB = make_fastdiv((uint32_t)g.TB);
     a.tilesN = 1;
     a.tr = g.tr;
     a.fP = make_fastdiv((uint32_t)a.P);

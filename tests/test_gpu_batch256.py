@@ -58,7 +58,7 @@ def test_batch256_train_step_node_parity_with_production_dispatch():
     print('kernels of the batch-256 step:', sorted(names))
     # the kernels that carry the benchmark, by name: the wide-tile ping-pong forward / input gradient and weight gradient, the
     # flat-image kernel of the 35x35 stage, the row-streaming stem kernels, the persistent kernel of the 8x8 layers
-    for must in ('conv_pp2<', 'conv_wgrad_pp<', 'conv_flat<', 'conv_wgrad_rows<', 'conv_wgrad_stem', 'conv_rows3x3<', 'conv_ws<', 'bn_bwd', 'bn_apply_kernel'):
+    for must in ('conv_pp2<', 'conv_slab<', 'conv_wgrad_pp<', 'conv_flat<', 'conv_wgrad_rows<', 'conv_wgrad_stem', 'conv_rows3x3<', 'conv_ws<', 'bn_bwd', 'bn_apply_kernel'):
         assert _has(names, must), (must, sorted(names))
     # ---- every node of the plan against the oracle, on the HIP path's own inputs
     worst = check_plan(hip, B, mask)

@@ -153,7 +153,7 @@ def _check_forward_and_input_gradient(ctx, case, lx, ly, prefix):
     assert torch.allclose(part[:, 1].sum(0).cpu(), (yh * yh).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
     if ly:
         assert torch.isnan(yb[..., :ly // 2].float()).all() and torch.isnan(yb[..., ly // 2 + K:].float()).all()
-    # ---- eval epilogue: affine + residual + ReLU
+    # ---- eval epilogue: affine + residual + ReLU (conv_slab serves training programs only: this call takes another kernel there)
     g = torch.Generator().manual_seed(3)
     scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
     res = _bf(torch.randn(N, P, Q, K, generator=g))
