@@ -574,9 +574,9 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
             return ifcbk_conv_flat_launch(ctx, &a, N, st);
     }
     // stride-1 multi-tap layers of the 17x17 class: the pixel-slab kernel (conv_slab.hip); every epilogue but the table / segment forms.
-    // Training programs only (forward + statistics, input gradients): its reduction order differs from the other kernels', and an
-    // eval batch must equal its parts bit for bit whichever kernel a batch size selects -- the eval forward keeps one summation order
-    if (big_ok(a) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && !a.ep_scale && a.PQ > 0) {
+    // Its reduction order differs from the other kernels' (same products, fp32 sums in another order), so the plan looks at the layer's
+    // shape only: whatever the batch, such a layer always takes this kernel, and an eval batch equals its parts bit for bit
+    if (big_ok(a) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && a.PQ > 0) {
         const int N = a.M / a.PQ;
         if (ifcbk_conv_slab_plan(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
             return ifcbk_conv_slab_launch(ctx, &a, N, st);

@@ -507,7 +507,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 snprintf(name, cap, "conv_flat<%d, %d, %d, %d, 0>", d.C, d.K, d.R, d.S);
                 break;
             }
-            if (!rows && d.stride_h == 1 && d.stride_w == 1 && o->kind == IFCBK_OP_CONV_FWD) {
+            if (!rows && d.stride_h == 1 && d.stride_w == 1) {
                 if (const int smt = ifcbk_conv_slab_plan(d.dtype, d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.pad_h, d.pad_w, d.P, d.Q)) {
                     snprintf(name, cap, "conv_slab<%d, %d, %d, %d, 50, 0>", d.K <= 128 ? 2 : 3, smt, smt == 10 ? 4 : smt / 2, d.R * d.S);
                     break;

@@ -16,7 +16,7 @@ from ._lib import Op, ConvDesc, BnDesc, PoolDesc, HeadDesc, RoiDesc
 
 
 # environment switches the library's conv dispatch reads per launch (csrc/conv_igemm.hip, conv_big.hip, conv_flat.hip, conv_wgrad*.hip)
-_DISPATCH_SWITCHES = ('IFCBK_FWD_LANES', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
+_DISPATCH_SWITCHES = ('IFCBK_FWD_LANES', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_WGRAD_LANE', 'IFCBK_WGRAD_GROUP', 'IFCBK_WGRAD_GROUP_MINKH', 'IFCBK_CONV_BIG', 'IFCBK_CONV_SLAB', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_CONV_FLAT', 'IFCBK_CONV_NT',
                       'IFCBK_CONV_WM', 'IFCBK_CONV_MQ', 'IFCBK_CONV_WS', 'IFCBK_CONV_WS_TILES', 'IFCBK_CONV_ROWS', 'IFCBK_WGRAD_PP',
                       'IFCBK_WGRAD_PP_KH', 'IFCBK_WGRAD_COLS', 'IFCBK_WGRAD_STEM', 'IFCBK_WGRAD_ROUNDS')
 

@@ -153,7 +153,7 @@ def _check_forward_and_input_gradient(ctx, case, lx, ly, prefix):
     assert torch.allclose(part[:, 1].sum(0).cpu(), (yh * yh).sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
     if ly:
         assert torch.isnan(yb[..., :ly // 2].float()).all() and torch.isnan(yb[..., ly // 2 + K:].float()).all()
-    # ---- eval epilogue: affine + residual + ReLU (conv_slab serves training programs only: this call takes another kernel there)
+    # ---- eval epilogue: affine + residual + ReLU
     g = torch.Generator().manual_seed(3)
     scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
     res = _bf(torch.randn(N, P, Q, K, generator=g))
@@ -204,7 +204,7 @@ def test_wide_tile_producer_table_and_segmented_epilogues(ctx, forced):
     """MODE 5 (BN-backward sums of a CONCATENATION's producers through a per-chunk table) and MODE 4 (eval sibling GEMM: segments
     with their own destination, stride and affine-or-raw switch) on the wide-tile kernel, shapes with M and K tails."""
     from ifcb_classifier_amd import _lib
-    forced(IFCBK_CONV_BIG=2, IFCBK_CONV_BIG_MT=8, IFCBK_CONV_BIG_TN=3, IFCBK_CONV_FLAT=0)
+    forced(IFCBK_CONV_BIG=2, IFCBK_CONV_BIG_MT=8, IFCBK_CONV_BIG_TN=3, IFCBK_CONV_FLAT=0, IFCBK_CONV_SLAB=0)
     case = (3, 168, 13, 11, 152, 1, 1, 1, 1, 0, 0)
     N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
     x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 5)
@@ -320,7 +320,7 @@ PP3 = [
 @pytest.mark.parametrize('case,grid,lx,ly', PP3)
 def test_persistent_wide_tile_kernel_forced(ctx, forced, case, grid, lx, ly):
     from ifcb_classifier_amd import _lib
-    env = dict(IFCBK_CONV_PP3=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_BIG=0)
+    env = dict(IFCBK_CONV_PP3=2, IFCBK_CONV_FLAT=0, IFCBK_CONV_BIG=0, IFCBK_CONV_SLAB=0)
     if grid:
         env['IFCBK_CONV_PP3_GRID'] = grid
     forced(**env)
@@ -376,7 +376,7 @@ def test_persistent_wide_tile_kernel_forced(ctx, forced, case, grid, lx, ly):
         assert _rel(y2v.float().cpu(), want) < 4e-3
         # ... bit for bit what the LDS-staged epilogue of conv_pp2 / conv_igemm writes: a RUN batch gets the same scores whichever
         # kernel its size selects
-        forced(IFCBK_CONV_PP3=0, IFCBK_CONV_FLAT=0)
+        forced(IFCBK_CONV_PP3=0, IFCBK_CONV_FLAT=0, IFCBK_CONV_SLAB=0)
         y3 = torch.full((N, P, Q, LDY), float('nan'), dtype=torch.bfloat16, device='cuda')
         y3p, y3v = _slice(y3, ly // 2, K)
         ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), xp, _lib.ptr(wk), y3p, _lib.ptr(scd), _lib.ptr(shd), None, 0, relu, st)
