@@ -169,6 +169,15 @@ int ifcbk_conv_big_launch(ifcbk_ctx* ctx, void* conv_args, int mt, int tn, hipSt
 bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh, int* nsplit, int* split_len);
 int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
                           int split_len, hipStream_t st);
+// conv_wgrad_flat.hip: flat-slot weight gradient (one filter row per block, x slab shared by the row's taps)
+bool ifcbk_wgrad_flat_plan(const ifcbk_conv_desc* d, int* nsplit, int* split_len);
+int ifcbk_wgrad_flat_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int nsplit, int split_len,
+                            hipStream_t st);
+bool ifcbk_wgrad_flat_member(const ifcbk_conv_desc* d);
+bool ifcbk_wgrad_flat_group_plan(int n, const ifcbk_conv_desc* ds, int* nsplit, int* split_len, int* tiles, size_t* slab_off, size_t* ws,
+                                 int* blocks);
+int ifcbk_wgrad_flat_group_launch(ifcbk_ctx* ctx, int n, const ifcbk_conv_desc* ds, const void* const* xs, const void* const* dys,
+                                  const int* nsplit, const int* split_len, const size_t* slab_off, hipStream_t st);
 // conv_flat.hip: flat-image kernel for stride-1 3x3 / 5x5 layers with 48..96 channels; returns its BatchNorm partial rows (= persistent grid; 0: not served)
 int ifcbk_conv_flat_rows(int dtype, int N, int H, int W, int cin, int kout, int R, int S, int ph, int pw, int P, int Q);
 int ifcbk_conv_flat_launch(ifcbk_ctx* ctx, void* conv_args, int N, hipStream_t st);

@@ -777,11 +777,11 @@ int pick_mt(int K, int maxmt) {
     return best;
 }
 
-struct Plan { int mt, cols, stem, tilesM, tilesN, nsplit, split_len; size_t ws; int pp; };
+struct Plan { int mt, cols, stem, tilesM, tilesN, nsplit, split_len; size_t ws; int pp, flat; };
 
 Plan make_plan(const ifcbk_conv_desc* d) {
     Plan p;
-    p.pp = 0;
+    p.pp = 0; p.flat = 0;
     const int bkp = d->dtype == IFCBK_F32 ? F_BKP : BKP;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     int RSC = d->R * d->S * d->C;
@@ -801,6 +801,18 @@ Plan make_plan(const ifcbk_conv_desc* d) {
         d->pad_h == d->pad_w && d->pad_h <= 1 && d->K % 32 == 0 && d->K <= 512) {
         if (d->C == 32 && d->Q <= 160 && d->W <= 166 && d->K <= 64) p.stem = 1;
         else if (d->C == 80 && d->Q <= 96 && d->W <= 102 && stem >= 2) p.stem = 2;
+    }
+    if (p.stem != 1) {
+        // flat-slot kernel (conv_wgrad_flat.hip): the stride-1 multi-tap layers over 48..96 input channels (35x35 stage, Conv2d_4a)
+        int ns = 0, len = 0;
+        if (ifcbk_wgrad_flat_plan(d, &ns, &len)) {
+            p.flat = 1; p.stem = 0; p.cols = 2;
+            p.mt = (cdiv(cdiv(d->K, cdiv(d->K, 96)), 16) * 16 + 31) / 32;
+            p.tilesM = cdiv(d->K, 96); p.tilesN = d->R;
+            p.nsplit = ns; p.split_len = len;
+            p.ws = (size_t)ns * d->K * RSC * sizeof(float);
+            return p;
+        }
     }
     if (p.stem) {
         const int kh = d->K / 32;
@@ -910,6 +922,8 @@ static int wgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, c
             case 3: hipLaunchKernelGGL(conv_wgrad_f32<3>, grid, block, 0, st, a); break;
             default: hipLaunchKernelGGL(conv_wgrad_f32<4>, grid, block, 0, st, a); break;
         }
+    } else if (p.flat) {
+        if (int e = ifcbk_wgrad_flat_launch(ctx, d, x, dy, (float*)ctx->ws, p.nsplit, p.split_len, st)) return e;
     } else if (p.pp) {
         if (int e = ifcbk_wgrad_pp_launch(ctx, d, x, dy, (float*)ctx->ws, p.pp, p.nsplit, p.split_len, st)) return e;
     } else if (p.stem) {

@@ -428,8 +428,10 @@ namespace {
 struct GroupPlan { int kh, nsplit[WPP_MAXG], split_len[WPP_MAXG], tiles[WPP_MAXG], blocks; size_t slab_off[WPP_MAXG], ws; };
 
 // channel tile of a member (the single-layer rule of ifcbk_wgrad_pp_plan) or 0 when the wide-tile kernel cannot take the layer
+constexpr int KH_FLAT = 16;      // pseudo channel tile: the member is a flat-slot layer (conv_wgrad_flat.hip)
 int group_member_kh(const ifcbk_conv_desc* d) {
     if (d->dtype != IFCBK_BF16 || d->Cw != d->C) return 0;
+    if (ifcbk_wgrad_flat_member(d)) return KH_FLAT;
     const int RSC = d->R * d->S * d->C;
     if (RSC % 4 || d->K % 8 || d->C % 8 || d->ldx % 8 || d->ldy % 8) return 0;
     if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31)) return 0;
@@ -463,9 +465,20 @@ bool group_plan(int n, const ifcbk_conv_desc* ds, GroupPlan* gp) {
         if (!k || (kh && k != kh)) return false;
         kh = k;
         gp->tiles[i] = cdiv(ds[i].K, 32 * kh) * cdiv(ds[i].R * ds[i].S * ds[i].C, 256);
-        steps[i] = ((int64_t)ds[i].N * ds[i].P * ds[i].Q + 63) / 64;
+        steps[i] = ((int64_t)ds[i].N * ds[i].P * ds[i].Q + 63) / 64;      // (flat-slot members: a lower bound of their slot steps; only the acceptance test below reads it)
     }
     const int cus = ifcbk_num_cus();
+    if (kh == KH_FLAT) {
+        // flat-slot members: two 256-thread blocks per CU; one grid over all their filter rows
+        if (!ifcbk_wgrad_flat_group_plan(n, ds, gp->nsplit, gp->split_len, gp->tiles, gp->slab_off, &gp->ws, &gp->blocks)) return false;
+        gp->kh = KH_FLAT;
+        if (mode < 2) {
+            if (gp->blocks < (3 * 2 * cus) / 4) return false;
+            for (int i = 0; i < n; ++i)
+                if (steps[i] / gp->nsplit[i] < 20) return false;
+        }
+        return true;
+    }
     int64_t lo = 1, hi = 1;
     for (int i = 0; i < n; ++i) hi = steps[i] > hi ? steps[i] : hi;
     auto blocks_at = [&](int64_t L) { int64_t b = 0; for (int i = 0; i < n; ++i) b += (int64_t)gp->tiles[i] * ((steps[i] + L - 1) / L); return b; };
@@ -530,10 +543,11 @@ extern "C" int ifcbk_conv2d_wgrad_group(ifcbk_ctx* ctx, int n, const ifcbk_conv_
     memset(&g, 0, sizeof(g));
     memset(&r, 0, sizeof(r));
     int blk = 0, rblk = 0;
+    const bool flat = gp.kh == KH_FLAT;
     for (int i = 0; i < n; ++i) {
         if ((uintptr_t)dws[i] % 16) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_group: dW of member %d is not 16-byte aligned", i);
         float* slab = (float*)((char*)ctx->ws + gp.slab_off[i]);
-        wpp_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh, gp.split_len[i]);
+        if (!flat) wpp_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh, gp.split_len[i]);
         g.blk0[i] = blk;
         blk += gp.tiles[i] * gp.nsplit[i];
         r.slab[i] = slab; r.dw[i] = dws[i]; r.nsplit[i] = gp.nsplit[i];
@@ -544,7 +558,8 @@ extern "C" int ifcbk_conv2d_wgrad_group(ifcbk_ctx* ctx, int n, const ifcbk_conv_
     for (int i = n; i <= WPP_MAXG; ++i) { g.blk0[i] = blk; r.blk0[i] = rblk; }
     g.n = n; r.n = n; r.accumulate = accumulate;
     const dim3 grid((unsigned)blk), block(512);
-    if (gp.kh == 4) hipLaunchKernelGGL((conv_wgrad_ppg<4>), grid, block, 0, st, g);
+    if (flat) { if (int e = ifcbk_wgrad_flat_group_launch(ctx, n, descs, xs, dys, gp.nsplit, gp.split_len, gp.slab_off, st)) return e; }
+    else if (gp.kh == 4) hipLaunchKernelGGL((conv_wgrad_ppg<4>), grid, block, 0, st, g);
     else if (gp.kh == 5) hipLaunchKernelGGL((conv_wgrad_ppg<5>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((conv_wgrad_ppg<6>), grid, block, 0, st, g);
     IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_ppg");

@@ -578,6 +578,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 snprintf(name, cap, "conv_wgrad_pp<%d, 0>", -mt);          // the name rocprofv3 lists: <KH, DM>
             }
             else if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
+            else if (cols == 2) snprintf(name, cap, "conv_wgrad_flat");
             else if (mt == 0) snprintf(name, cap, "conv_wgrad_stem");
             else if (cols) snprintf(name, cap, "conv_wgrad_cols<%d, 4>", mt);
             else snprintf(name, cap, "conv_wgrad_rows<%d>", mt);
@@ -590,7 +591,10 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
             int kh = 0;
             if (it && n >= 1 && n <= 8) {
                 for (int k = 0; k < n; ++k) ds[k] = it[k].d;
-                if (ifcbk_conv2d_wgrad_group_info(n, ds, &kh, nullptr, nullptr) == IFCBK_OK) snprintf(name, cap, "conv_wgrad_ppg<%d>", kh);
+                if (ifcbk_conv2d_wgrad_group_info(n, ds, &kh, nullptr, nullptr) == IFCBK_OK) {
+                    if (kh == 16) snprintf(name, cap, "conv_wgrad_flatg");
+                    else snprintf(name, cap, "conv_wgrad_ppg<%d>", kh);
+                }
             }
             break;
         }

@@ -871,6 +871,21 @@ class Engine:
         WLs = list(range(NL - self.wgrad_lane, NL))        # the weight-gradient lanes
         wl_next = [0]
         lane_of = assign_lanes(NL - self.wgrad_lane)
+        # The TRUNK: the single-chain prefix of the network (inception's stem Conv2d_1a .. 4a + its pools).  Its backward is the end
+        # of the step -- one chain lane busy, the other chain lanes idle -- and its weight gradients (1.0 ms of kernels when each
+        # runs alone) used to queue up on the one weight-gradient lane behind each other.  Round 5: they go round-robin over ALL
+        # lanes but the trunk's own, so that the weight gradients of 4a / 2b / 2a overlap each other beside the trunk's chain
+        # (IFCBK_WGRAD_SPREAD=1; measured on one box, three interleaved rounds: 21.44 vs 21.45 ms per step -- no gain: those kernels cost the step their CU-time, not their queueing -- so the default stays 0: one weight-gradient lane for everything, as in round 4)
+        trunk = set()
+        if self.wgrad_lane and NL - self.wgrad_lane >= 2 and os.environ.get('IFCBK_WGRAD_SPREAD', '0') != '0':
+            body = [m for m in net.nodes if not m.aux and m.kind != 'head']
+            if body:
+                for m in body:
+                    if lane_of[m] != lane_of[body[0]]:
+                        break
+                    trunk.add(m)
+        TLs = [l for l in range(NL - 1, -1, -1) if not trunk or l != lane_of[next(iter(trunk))]] if trunk else []
+        tl_next = [0]
         # the forward has no weight gradients: IFCBK_FWD_LANES lets its branches use the weight-gradient lane(s) too
         fwd_lanes = max(1, min(NL, int(os.environ.get('IFCBK_FWD_LANES', str(NL - self.wgrad_lane)))))
         lane_fwd = assign_lanes(fwd_lanes) if fwd_lanes != NL - self.wgrad_lane else lane_of
@@ -1305,7 +1320,10 @@ class Engine:
                 elif self.wgrad_lane:
                     draw = _vp(group_draw(n.group), self.esize * n.koff)
                 LW = None                                 # lane of this node's weight gradient (None: the node's own lane)
-                if self.wgrad_lane:
+                if self.wgrad_lane and n in trunk:
+                    LW = TLs[tl_next[0] % len(TLs)]       # (the trunk's weight gradients: every lane but the trunk's own)
+                    tl_next[0] += 1
+                elif self.wgrad_lane:
                     LW = WLs[wl_next[0] % len(WLs)]       # (round-robin over the weight-gradient lanes, per NODE)
                     wl_next[0] += 1
                 ckey, bkey = n.conv_key + '.weight', n.bn_key
@@ -1432,6 +1450,7 @@ class Engine:
         pl = PlanObj()
         pl.N = N
         pl.fwd_train, pl.fwd_eval, pl.bwd = Program(fwd_t), Program(fwd_e), Program(bwd)
+        pack_ops = pack                                # one OP_WEIGHT_PACK per conv (the bucketed update cuts this list)
         pack = self._pack_multi(pack)
         pl.pack, pl.evalprep = Program(pack), Program(evalprep)
         # loss ops: CE(main) + 0.4*CE(aux)   (neuston_models.py:70-78)
@@ -1462,12 +1481,14 @@ class Engine:
         # the step's bookkeeping in the step's own op table: num_batches_tracked += 1 of every BatchNorm, loss_sum += loss
         cnt = OpList()
         cnt.add(_lib.OP_STEP_COUNTERS, 'step_counters', p=(_vp(self.nbt), _vp(self.loss_sum), _vp(self.loss)), i=(self.nbt.numel(),))
-        # fused train step = fwd + loss + bwd + adam + pack (+ counters)
+        # fused train step = fwd + loss + bwd + adam + pack (+ counters); round 5: the optimizer and the repack run PER BUCKET of the
+        # flat gradient buffer, on the weight-gradient lane, as soon as backward has finished the bucket (_bucketed_update)
         allops = OpList()
-        for prog_ops in (fwd_t, lossl, bwd, opt, pack, cnt):
+        for prog_ops in (fwd_t, lossl) + self._bucketed_update(bwd, opt, pack_ops) + (cnt,):
             allops.extend(prog_ops)
         pl.step = Program(allops)
-        pl.step_adam_idx = pl.step.find(_lib.OP_SGD if self.optimizer == 'sgd' else _lib.OP_ADAM)[0]
+        pl.step_adam_idxs = pl.step.find(_lib.OP_SGD if self.optimizer == 'sgd' else _lib.OP_ADAM)
+        pl.step_adam_idx = pl.step_adam_idxs[-1]
         # data-parallel variant: fwd+loss | backward segments (all-reduce launched after each) | adam+pack
         fl = OpList()
         fl.extend(fwd_t)
@@ -1488,10 +1509,101 @@ class Engine:
         pl.keep = keep
         return pl
 
-    def _pack_multi(self, pack):
-        """fold the per-conv weight_pack ops into ONE multi-tensor launch (device-side item table, built once)."""
+    def _bucketed_update(self, bwd, opt, pack_ops):
+        """-> (backward ops with the optimizer + repack of every finished gradient bucket inserted, the last bucket's optimizer, its
+        repack).  Backward finishes the flat gradient buffer from its tail (dp.segment_plan: the cuts of the data-parallel exchange);
+        a bucket's optimizer op and the repack of its conv weights go onto the weight-gradient lane right behind the ops that
+        complete it -- and behind the last input-gradient op that reads a bf16 shadow of the bucket (the shadow is rewritten by the
+        repack) -- so that only the last bucket (the stem: 4 % of the parameters) is updated behind the end of backward.  Same
+        arithmetic per element as one launch over the whole buffer (Adam / SGD are element-wise; the step count is a launch
+        argument of every bucket's op).  IFCBK_OPT_BUCKETS: target number of buckets (6), <= 1 = one launch at the end."""
+        nb = int(os.environ.get('IFCBK_OPT_BUCKETS', '6'))
+        whole = (bwd, opt, self._pack_multi(pack_ops))
+        if nb <= 1 or self.wgrad_side_lane:
+            return whole
+        from .dp import segment_plan
+        offs = [self._op_param_offsets(o) for o in bwd.ops]
+        try:
+            segs = segment_plan(offs, self.palloc, self.nparam_padded, nb)
+        except RuntimeError:
+            return whole
+        if len(segs) < 2:
+            return whole
+        # which parameters' shadows does an input-gradient op read?  (a sibling group's op: every member's)
+        pbase, sbase = self.P.data_ptr(), self.Wsh.data_ptr()
+        regions = [(g.wT_off, g.wT_off + g.Ktot * g.x.C) for g in self.groups]
+
+        def skey(elem_off):
+            for (r0, r1) in regions:
+                if r0 <= elem_off < r1:
+                    return r0
+            return elem_off
+        owners = {}
+        for o in pack_ops.ops:
+            if o.p[2]:
+                owners.setdefault(skey((o.p[2] - sbase) // self.esize), []).append((o.p[0] - pbase) // 4)
+        dkinds = (_lib.OP_CONV_DGRAD, _lib.OP_CONV_DGRAD_BNSTAT, _lib.OP_CONV_DGRAD_BNSTAT_TAB)
+        last_reader = {}                       # parameter offset -> index of the last backward op that reads its shadow
+        shreads = {}                           # backward op index -> [('SH', off, off + size)]
+        for k, o in enumerate(bwd.ops):
+            if o.kind in dkinds:
+                own = owners.get(skey((o.p[1] - sbase) // self.esize))
+                if own is None:
+                    return whole               # an input gradient whose filter this plan cannot attribute: keep the single update
+                shreads[k] = [('SH', off, off + self.palloc[off]) for off in own]
+                for off in own:
+                    last_reader[off] = k
+        LW = self.NL - 1 if self.wgrad_lane else 0
+        inserts = {}                           # op index -> OpList to emit BEFORE that op (i.e. behind op index - 1)
+        prev_ins = 0
+        for (b0, b1, lo, hi) in segs[:-1]:
+            ins = max([b1, prev_ins] + [1 + k for off, k in last_reader.items() if lo <= off < hi])
+            prev_ins = ins
+            ol = inserts.setdefault(ins, OpList())
+            o0 = opt.ops[0]
+            ptrs = [(o0.p[j] + 4 * lo) if o0.p[j] else None for j in range(4 if self.optimizer != 'sgd' else 3)]
+            ol.add(o0.kind, opt.tags[0] + '[%d:%d]' % (lo, hi), p=ptrs, i=(hi - lo, int(o0.i[1])), f=tuple(o0.f[j] for j in range(8)),
+                   lane=LW, reads=[('G', lo, hi)], writes=[('P', lo, hi)])
+            sub = OpList()
+            for o, tg, mt in zip(pack_ops.ops, pack_ops.tags, pack_ops.meta):
+                if lo <= (o.p[0] - pbase) // 4 < hi:
+                    sub.ops.append(o); sub.tags.append(tg); sub.meta.append(mt)
+            if sub.ops:
+                pm = self._pack_multi(sub, key=(lo, hi))
+                pm.meta[0] = (LW, [('P', lo, hi)], [('SH', lo, hi)])
+                ol.extend(pm)
+        out = OpList()
+        for k, (o, tg, mt) in enumerate(zip(bwd.ops, bwd.tags, bwd.meta)):
+            if k in inserts:
+                out.extend(inserts[k])
+            lane, reads, writes = mt
+            if not (reads is None and writes is None):
+                extra_w = [('G', off, off + self.palloc[off]) for off in offs[k]]
+                mt = (lane, list(reads or ()) + shreads.get(k, []), list(writes or ()) + extra_w)
+            out.ops.append(o); out.tags.append(tg); out.meta.append(mt)
+        for k in sorted(inserts):
+            if k >= len(bwd.ops):
+                out.extend(inserts[k])
+        # the last bucket: behind the end of backward, as full barriers (as the single update was)
+        lo, hi = segs[-1][2], segs[-1][3]
+        last_opt, last_pack = OpList(), OpList()
+        o0 = opt.ops[0]
+        ptrs = [(o0.p[j] + 4 * lo) if o0.p[j] else None for j in range(4 if self.optimizer != 'sgd' else 3)]
+        last_opt.add(o0.kind, opt.tags[0] + '[%d:%d]' % (lo, hi), p=ptrs, i=(hi - lo, int(o0.i[1])), f=tuple(o0.f[j] for j in range(8)))
+        sub = OpList()
+        for o, tg, mt in zip(pack_ops.ops, pack_ops.tags, pack_ops.meta):
+            if lo <= (o.p[0] - pbase) // 4 < hi:
+                sub.ops.append(o); sub.tags.append(tg); sub.meta.append(mt)
+        if sub.ops:
+            last_pack = self._pack_multi(sub, key=(lo, hi))
+        return (out, last_opt, last_pack)
+
+    def _pack_multi(self, pack, key=None):
+        """fold the per-conv weight_pack ops into ONE multi-tensor launch (device-side item table, built once per ``key``:
+        None = every conv of the network, (lo, hi) = the convs of one optimizer bucket)."""
         import numpy as np
-        if getattr(self, '_pack_items', None) is None:
+        cache = self.__dict__.setdefault('_pack_tables', {})
+        if key not in cache:
             items = (_lib.PackItem * len(pack.ops))()
             blk = 0
             for k, o in enumerate(pack.ops):
@@ -1503,11 +1615,13 @@ class Engine:
                 it.first_block = blk
                 blk += ((d.K + 31) // 32) * d.R * d.S * ((d.C + 31) // 32)      # 32x32 (k, c) tiles per filter tap
             raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
-            self._pack_items = torch.from_numpy(raw).to(self.dev)
-            self._pack_n, self._pack_blocks = len(pack.ops), blk
+            cache[key] = (torch.from_numpy(raw).to(self.dev), len(pack.ops), blk)
+        tab, n, blocks = cache[key]
+        if key is None:
+            self._pack_items, self._pack_n, self._pack_blocks = tab, n, blocks
         out = OpList()
-        out.add(_lib.OP_WEIGHT_PACK_MULTI, 'weight_pack', p=(_vp(self._pack_items),),
-                i=(self._pack_n, self._pack_blocks, self.cdtype))
+        out.add(_lib.OP_WEIGHT_PACK_MULTI, 'weight_pack' + ('' if key is None else '[%d:%d]' % key), p=(_vp(tab),),
+                i=(n, blocks, self.cdtype))
         return out
 
     def _op_param_offsets(self, o):
@@ -1757,14 +1871,16 @@ class Engine:
         self.ensure_packed(pl)
         self.make_dropout_mask(N)
         self.step_count += 1
-        self._set_update(pl.step.arr[pl.step_adam_idx])
+        for j in pl.step_adam_idxs:
+            self._set_update(pl.step.arr[j])
         if ev_slot is not None:
             # ev_arr: pl.step.timed(...) -- which ops to bracket with HIP events (default: all)
             if ev_arr is None:
                 if getattr(pl, 'step_timed_all', None) is None:
                     pl.step_timed_all = pl.step.timed()
                 ev_arr = pl.step_timed_all
-            self._set_update(ev_arr[pl.step_adam_idx])
+            for j in pl.step_adam_idxs:
+                self._set_update(ev_arr[j])
             self.ctx.call('ifcbk_run_program_ev', ev_arr, pl.step.n, self.stream(), int(ev_slot))
         elif self.graph_train and op_ms is None:
             # fwd + loss + bwd replayed as one hipGraph; Adam (its step count is a launch argument) + repack stay plain launches

@@ -41,7 +41,7 @@ def _kname(ctx, d, kind, flags=0, residual=False):
 def forced(monkeypatch):
     def set_(**kw):
         for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
-                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_CONV_SLAB'):
+                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_CONV_SLAB', 'IFCBK_WGRAD_FLAT'):
             monkeypatch.delenv(k, raising=False)
         for k, v in kw.items():
             monkeypatch.setenv(k, str(v))
@@ -299,6 +299,87 @@ def test_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
     ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 1, st)      # accumulate
     torch.cuda.synchronize()
     assert _rel(dw.cpu(), 2 * rdw) < 1e-4
+
+
+# the flat-slot weight gradient (conv_wgrad_flat.hip, round 5): one filter row per block, the x slab shared by the row's taps.  3x3
+# and 5x5 with padding (band slots between rows / images), the unpadded Conv2d_4a shape (two K tiles of 96), K and column tails
+# (K = 40: 48-channel tile; 15 column tiles: an odd count over the two wave columns), slices, pixel counts off the 64-slot step
+WFLAT = [
+    ((4, 64, 19, 17, 96, 3, 3, 1, 1, 1, 1), 0, 0),               # the 35x35 stage's 64 -> 96
+    ((3, 96, 14, 21, 96, 3, 3, 1, 1, 1, 1), 8, 16),              # 96 -> 96: 18 column tiles, slices
+    ((3, 48, 15, 15, 64, 5, 5, 1, 1, 2, 2), 0, 8),               # 5x5: 15 column tiles, five filter rows
+    ((2, 80, 23, 25, 192, 3, 3, 1, 1, 0, 0), 0, 0),              # Conv2d_4a: no padding, two K tiles
+    ((3, 64, 13, 13, 40, 3, 3, 1, 1, 1, 1), 0, 0),               # K tail: 40 of a 48-channel tile
+    ((2, 16, 10, 11, 24, 3, 3, 1, 1, 1, 1), 8, 0),               # tiny: 3 column tiles, one wave column partly empty
+    ((2, 32, 9, 30, 104, 1, 7, 1, 1, 0, 3), 0, 0),               # one filter row of seven taps, K = 104: two K tiles of 64 (52 -> 64)
+]
+
+
+@pytest.mark.parametrize('case,lx,ly', WFLAT)
+def test_flat_slot_weight_gradient_forced(ctx, forced, case, lx, ly):
+    from ifcb_classifier_amd import _lib
+    forced(IFCBK_WGRAD_FLAT=2)
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 41, lx, ly)
+    d = _desc(case, P, Q, LDX, LDY)
+    assert _kname(ctx, d, _lib.OP_CONV_WGRAD) == 'conv_wgrad_flat', _kname(ctx, d, _lib.OP_CONV_WGRAD)
+    st = _lib.cur_stream()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, (sh, sw), (ph, pw)).backward(dy)
+    rdw = wr.grad.permute(0, 2, 3, 1)
+    xp, _ = _slice(xb, lx // 2, Cc)
+    dyp, _ = _slice(dyb, ly // 2, K)
+    ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
+    outs = []
+    for rep in range(2):                                               # (twice: bitwise repeatable)
+        dw = torch.full((K, R, S, Cc), float('nan'), device='cuda')
+        ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 0, st)
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[0], rdw) < 1e-4
+    err = (outs[0] - rdw).abs().max().item()
+    assert err <= 2e-5 * max(1.0, rdw.abs().max().item()) * (N * P * Q) ** 0.5, err
+    ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 1, st)      # accumulate
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu(), 2 * rdw) < 1e-4
+
+
+def test_flat_slot_weight_gradients_as_one_group(ctx, forced):
+    """three layers of one block (5x5 48 -> 64, 3x3 64 -> 96, 3x3 96 -> 96) as ONE grid + one reduce: equal, bit for bit, to their
+    single launches (same per-block sums, same reduce order); ifcbk_op_kernel names the grouped kernel"""
+    from ifcb_classifier_amd import _lib
+    forced(IFCBK_WGRAD_FLAT=2, IFCBK_WGRAD_PP=2)
+    cases = [(6, 48, 15, 15, 64, 5, 5, 1, 1, 2, 2), (6, 64, 15, 15, 96, 3, 3, 1, 1, 1, 1), (6, 96, 15, 15, 96, 3, 3, 1, 1, 1, 1)]
+    n = len(cases)
+    st = _lib.cur_stream()
+    descs = (_lib.ConvDesc * n)()
+    xs, dys, dws, keep, single = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), [], []
+    for i, case in enumerate(cases):
+        N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+        x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 50 + i)
+        d = _desc(case, P, Q, LDX, LDY)
+        descs[i] = d
+        assert ctx.lib.ifcbk_conv2d_wgrad_group_member_kh(C.byref(d)) == 16
+        ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
+        dw1 = torch.full((K, R, S, Cc), float('nan'), device='cuda')
+        ctx.call('ifcbk_conv2d_wgrad', C.byref(d), _lib.ptr(xb), _lib.ptr(dyb), _lib.ptr(dw1), 0, st)
+        torch.cuda.synchronize()
+        single.append(dw1.cpu())
+        dwg = torch.full((K, R, S, Cc), float('nan'), device='cuda')
+        xs[i], dys[i], dws[i] = xb.data_ptr(), dyb.data_ptr(), dwg.data_ptr()
+        keep.append((xb, dyb, dwg))
+    need = ctx.lib.ifcbk_conv2d_wgrad_group_workspace(n, descs)
+    assert need > 0
+    ctx.reserve(need)
+    kh = C.c_int(0)
+    assert ctx.lib.ifcbk_conv2d_wgrad_group_info(n, descs, C.byref(kh), None, None) == 0 and kh.value == 16
+    ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 0, st)
+    torch.cuda.synchronize()
+    for i in range(n):
+        got = keep[i][2].cpu()
+        assert _rel(got, single[i]) < 1e-6
+        # (the split counts of the group differ from the single launches': the same products summed in another split order)
 
 
 # conv_pp3 (round 4): the PERSISTENT wide-tile kernel -- seamless tile switch, deferred register-direct stores, statistics by DPP row
