@@ -40,10 +40,6 @@ struct WppArgs {
     int split_len;    // pixels per split (multiple of 64)
     int tilesJ, tiles;
     fastdiv_t fPQ, fQ;
-    // flat-slot form (wpf_run, round 5): the reduction runs over the padded flat slots of conv_slab.hip (either axis minor)
-    int MajP, MinP, ImgP, pa, pb, OA, OB, N, G;      // slot geometry; G = N * ImgP slots
-    int sa, sb, simg, dsa, dsb, dsimg;               // element strides of x / dy along (major, minor, image)
-    fastdiv_t fImg, fLine;
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -282,179 +278,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_pp(WppArgs a) {
     wpp_run<KH, DM>(a, (int)xcd_remap(blockIdx.x, gridDim.x));
 }
 
-// ---------------------------------------------------------------- flat-slot form for the 7-tap layers (round 5)
-// The same ping-pong block, with the x operand taken out of the per-tap gather: a tile is (32*KH) output channels x ALL S taps of ONE
-// 64-channel chunk (S * 64 columns: 448 for the 1x7 / 7x1 layers), and the reduction runs over the flat slots of conv_slab.hip (slot
-// (n*MajP + a + pa)*MinP + b + pb, b = the axis the filter extends along; an output pixel is slot (n*MajP + oa)*MinP + ob and tap t of
-// ANY output slot reads slot + t).  A 64-slot step then needs its dy rows (zeros at band slots, through out-of-range offsets) and
-// ONE x slab of 64 + S - 1 slots x 64 channels -- the S taps are that slab read at row offsets 0..S-1, per-lane constant addresses --
-// instead of one gathered 64-row sub-tile per 64 columns: per wave and step NSA + 1 LDS-DMA pieces (+ 1 for one wave: rows 64..71)
-// for 2 * S * KH MFMAs, against NSA + 4 pieces for 2 * 4 * KH.  KH = 3 (K = 192 as two tiles of 96): 25 pieces per 1,344 cycles of MFMA
-// per step and CU -- conv_wgrad_pp<6>: 56 per 1,536.  Wave (G, wc): channel half G of the tile, 16-channel group wc of the chunk, all
-// S taps: S x KH accumulator tiles.  Band slots (3 of 20 per line of a 17x17 map) multiply zeros: 15 % of the MFMAs.
-template <int KH, int S>
-__device__ __forceinline__ void wpf_run(const WppArgs& a, const int lin) {
-    constexpr int BMK = 32 * KH;
-    constexpr int NSA = (BMK + 63) / 64;             // dy sub-tiles
-    constexpr int SUB = 64 * 128;
-    constexpr int SLABB = 72 * 128;                  // x slab: 64 + S - 1 <= 72 rows of 128 B
-    constexpr int PARB = NSA * SUB + SLABB;
-    static_assert(S >= 2 && S <= 9, "slab rows");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PARB];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int grp = wave >> 2, wc = wave & 3;
-    const int split = lin / a.tiles;
-    const int tile = lin - split * a.tiles;
-    const int ktile = tile / a.tilesJ, cc = tile - ktile * a.tilesJ;
-    const int k0 = ktile * BMK, c0 = cc * 64;
-    const int g_begin = split * a.split_len;
-    const int g_end = min(g_begin + a.split_len, a.G);
-    const int nsteps = (g_end - g_begin + 63) / 64;
-
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.xbytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    const int lrow8 = lane >> 3;
-    const int csrc = (lane & 7) ^ lrow8;
-    unsigned acol[NSA];
-#pragma unroll
-    for (int s = 0; s < NSA; ++s) {
-        const int ch = s * 64 + csrc * 8;
-        acol[s] = (ch < BMK && k0 + ch < a.K) ? (unsigned)(k0 + ch) * 2u : OOB;
-    }
-    const unsigned xcol = (c0 + csrc * 8 < a.C) ? (unsigned)(c0 + csrc * 8) * 2u : OOB;
-    unsigned pxoff = OOB, pdyoff = OOB;
-    int tgt = 0;
-    // slot -> byte offsets of its dy row (OOB: band slot / beyond the split) and of its x row (OOB: band slot / beyond the tensor)
-#define WPF_SLOT(SLOT, DYO, XO)                                                                                     \
-    {                                                                                                               \
-        const unsigned F = (unsigned)(SLOT);                                                                        \
-        const unsigned n = fdiv(F, a.fImg);                                                                         \
-        const unsigned rem = F - n * (unsigned)a.ImgP;                                                              \
-        const unsigned line = fdiv(rem, a.fLine);                                                                   \
-        const unsigned col = rem - line * (unsigned)a.MinP;                                                         \
-        const bool dv = tgt < nsteps && (int)F < g_end && (int)n < a.N && (int)line < a.OA && (int)col < a.OB;      \
-        DYO = dv ? (unsigned)((int)n * a.dsimg + (int)line * a.dsa + (int)col * a.dsb) * 2u : OOB;                  \
-        const int ia = (int)line - a.pa, ib = (int)col - a.pb;                                                      \
-        const bool xv = tgt < nsteps && (int)n < a.N && ia >= 0 && ib >= 0;                                         \
-        XO = xv ? (unsigned)((int)n * a.simg + ia * a.sa + ib * a.sb) * 2u : OOB;                                   \
-    }
-#define WPF_BATCH1()                                                                                                \
-    {                                                                                                               \
-        WPF_SLOT(g_begin + tgt * 64 + wave * 8 + lrow8, pdyoff, pxoff)                                              \
-        _Pragma("unroll") for (int i = 0; i < NSA; ++i) {                                                           \
-            unsigned char* dst = smem + (tgt & 1) * PARB + i * SUB + wave * 1024;                                   \
-            wpp_dma16(rsA, (lptr_t)dst, (pdyoff != OOB && acol[i] != OOB) ? pdyoff + acol[i] : OOB);                \
-        }                                                                                                           \
-    }
-#define WPF_BATCH2()                                                                                                \
-    {                                                                                                               \
-        unsigned char* dst = smem + (tgt & 1) * PARB + NSA * SUB + wave * 1024;                                     \
-        wpp_dma16(rsB, (lptr_t)dst, (pxoff != OOB && xcol != OOB) ? pxoff + xcol : OOB);                            \
-        if (wave == (tgt & 7)) {                     /* slab rows 64..71: one wave per step, in turn */             \
-            unsigned dyo2, xo2;                                                                                     \
-            WPF_SLOT(g_begin + tgt * 64 + 64 + lrow8, dyo2, xo2)                                                    \
-            (void)dyo2;                                                                                             \
-            wpp_dma16(rsB, (lptr_t)(smem + (tgt & 1) * PARB + NSA * SUB + 8 * 1024), (xo2 != OOB && xcol != OOB) ? xo2 + xcol : OOB); \
-        }                                                                                                           \
-        ++tgt;                                                                                                      \
-    }
-    constexpr int P1 = NSA;
-
-    // ---- prologue: step 0 completely; group 0 is one batch ahead (its first batch of step 1)
-    WPF_BATCH1() WPF_BATCH2()
-    if (grp == 0) WPF_BATCH1()
-
-    const int g = lane >> 4, lq = (lane >> 2) & 3, lp = lane & 3;
-    const int row0 = 4 * g + lq, rk = row0 & 7;
-    const unsigned sbase = (unsigned)(size_t)(lptr_t)smem;
-    unsigned xaddr[S], daddr[KH];
-#pragma unroll
-    for (int jt = 0; jt < S; ++jt) {
-        const int row = row0 + jt;
-        xaddr[jt] = sbase + NSA * SUB + (unsigned)(row * 128 + (((2 * wc + (lp >> 1)) ^ (row & 7)) * 16) + (lp & 1) * 8);
-    }
-#pragma unroll
-    for (int kt = 0; kt < KH; ++kt) {
-        const int ch = grp * 16 * KH + kt * 16;
-        const int ti = (ch >> 4) & 3;
-        daddr[kt] = sbase + (ch >> 6) * SUB + (unsigned)(row0 * 128 + (((2 * ti + (lp >> 1)) ^ rk) * 16) + (lp & 1) * 8);
-    }
-
-    f32x4_t acc[S][KH];
-#pragma unroll
-    for (int i = 0; i < S; ++i)
-#pragma unroll
-        for (int j = 0; j < KH; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    if (grp == 0) wpp_wait_vmcnt<P1>(); else wpp_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier behind group 0
-
-#define WPF_PHASE(KHV)                                                                                              \
-    {                                                                                                               \
-        s16x4_t xlo[S], xhi[S], dlo[KH], dhi[KH];                                                                   \
-        _Pragma("unroll") for (int jt = 0; jt < S; ++jt) WPP_TR(xlo[jt], xhi[jt], xaddr[jt] + paroff, (KHV) * 32 * 128) \
-        _Pragma("unroll") for (int kt = 0; kt < KH; ++kt) WPP_TR(dlo[kt], dhi[kt], daddr[kt] + paroff, (KHV) * 32 * 128) \
-        if (grp == 0) {                                                                                             \
-            if ((KHV) == 1) { WPF_BATCH1() wpp_wait_vmcnt<P1>(); } else { WPF_BATCH2() }                            \
-        } else {                                                                                                    \
-            if ((KHV) == 0) { WPF_BATCH1() wpp_wait_vmcnt<P1>(); } else { WPF_BATCH2() }                            \
-        }                                                                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        /* reads complete BEFORE the barrier (WAR, see the header) */ \
-        _Pragma("unroll") for (int jt = 0; jt < S; ++jt) asm volatile("" : "+v"(xlo[jt]), "+v"(xhi[jt]));           \
-        _Pragma("unroll") for (int kt = 0; kt < KH; ++kt) asm volatile("" : "+v"(dlo[kt]), "+v"(dhi[kt]));         \
-        __builtin_amdgcn_s_barrier();                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        __builtin_amdgcn_s_setprio(1);                                                                              \
-        {                                                                                                           \
-            bf16x8_t fx[S], fd[KH];                                                                                 \
-            _Pragma("unroll") for (int jt = 0; jt < S; ++jt)                                                        \
-                fx[jt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(xlo[jt], xhi[jt], 0, 1, 2, 3, 4, 5, 6, 7)); \
-            _Pragma("unroll") for (int kt = 0; kt < KH; ++kt)                                                       \
-                fd[kt] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(dlo[kt], dhi[kt], 0, 1, 2, 3, 4, 5, 6, 7)); \
-            _Pragma("unroll") for (int jt = 0; jt < S; ++jt)                                                        \
-                _Pragma("unroll") for (int kt = 0; kt < KH; ++kt)                                                   \
-                    acc[jt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[jt], fd[kt], acc[jt][kt], 0, 0, 0);    \
-        }                                                                                                           \
-        __builtin_amdgcn_s_setprio(0);                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        __builtin_amdgcn_s_barrier();                                                                               \
-        asm volatile("" ::: "memory");                                                                              \
-    }
-
-    for (int st = 0; st < nsteps; ++st) {
-        const unsigned paroff = (unsigned)(st & 1) * PARB;
-        WPF_PHASE(0)
-        WPF_PHASE(1)
-    }
-#undef WPF_PHASE
-#undef WPF_BATCH1
-#undef WPF_BATCH2
-#undef WPF_SLOT
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    wpp_wait_vmcnt<0>();                               // the tail's dummy pieces
-
-    // ---- slab store: a lane holds 4 consecutive channels c of tap jt for one output channel k per tile
-    float* out = a.slab + (size_t)split * a.K * a.RSC;
-    const int kl = lane & 15, jq = (lane >> 4) * 4;
-    const int c = c0 + wc * 16 + jq;
-#pragma unroll
-    for (int kt = 0; kt < KH; ++kt) {
-        const int k = k0 + grp * 16 * KH + kt * 16 + kl;
-#pragma unroll
-        for (int jt = 0; jt < S; ++jt)
-            if (k < a.K && c < a.C) *reinterpret_cast<f32x4_t*>(out + (size_t)k * a.RSC + jt * a.C + c) = acc[jt][kt];
-    }
-}
-
-template <int KH, int S>
-__global__ __launch_bounds__(512) void conv_wgrad_pps(WppArgs a) {
-    wpf_run<KH, S>(a, (int)xcd_remap(blockIdx.x, gridDim.x));
-}
-
 // ---- grouped launch: ONE grid over the weight gradients of up to WPP_MAXG layers (round 4).
 // A 17x17 layer's dW is 192 x 1344: six tiles.  Alone it needs 42 pixel splits to fill the chip -- 252 blocks of 27 K-steps that
 // each end in a 196 KB fp32 slab store (50 MB per launch written, then read back by wgrad_reduce: 1.68x the algorithmic bytes),
@@ -477,17 +300,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_ppg(WppGroup g) {
         if (q < g.n && bid >= g.blk0[q]) gi = q;
     const WppArgs a = g.a[gi];
     wpp_run<KH, 0>(a, bid - g.blk0[gi]);
-}
-
-template <int KH, int S>
-__global__ __launch_bounds__(512) void conv_wgrad_ppsg(WppGroup g) {
-    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
-    int gi = 0;
-#pragma unroll
-    for (int q = 1; q < WPP_MAXG; ++q)
-        if (q < g.n && bid >= g.blk0[q]) gi = q;
-    const WppArgs a = g.a[gi];
-    wpf_run<KH, S>(a, bid - g.blk0[gi]);
 }
 
 // slabs of every member -> its dW, one launch (the per-element sums are those of wgrad_reduce4: same order, same bits)
@@ -543,61 +355,6 @@ int wpp_mode() {
     return e ? atoi(e) : 1;
 }
 
-// IFCBK_WGRAD_PPS: 0 = never, 1 = the 7-tap layers of the 17x17 class (default), 2 = wherever the flat-slot form applies (tests)
-int pps_mode() {
-    const char* e = getenv("IFCBK_WGRAD_PPS");
-    return e ? atoi(e) : 1;
-}
-constexpr int KH_PPS = 32;       // pseudo channel tile KH_PPS + KH: the flat-slot form (wpf_run) with channel tile 32 * KH
-
-// channel tile (3, 4, 5) of the flat-slot form for this layer, 0: not served.  1x7 / 7x1, stride 1, symmetric padding.
-int pps_kh(const ifcbk_conv_desc* d) {
-    const int mode = pps_mode();
-    if (mode <= 0 || wpp_mode() <= 0 || d->dtype != IFCBK_BF16 || d->Cw != d->C) return 0;
-    if (d->stride_h != 1 || d->stride_w != 1) return 0;
-    if (!((d->R == 1 && d->S == 7) || (d->R == 7 && d->S == 1))) return 0;
-    if (d->pad_h < 0 || d->pad_w < 0 || d->pad_h > d->R - 1 || d->pad_w > d->S - 1) return 0;
-    if (d->P != d->H + 2 * d->pad_h - d->R + 1 || d->Q != d->W + 2 * d->pad_w - d->S + 1 || d->P < 1 || d->Q < 1) return 0;
-    if (d->C % 8 || d->K % 8 || d->ldx % 8 || d->ldy % 8) return 0;
-    if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31)) return 0;
-    if ((int64_t)(d->N + 1) * (d->H + d->pad_h) * (d->W + d->pad_w) + 4096 >= (1ll << 31)) return 0;
-    int kh = 0;
-    if (d->K % 96 == 0) kh = 3;
-    else if (d->K % 128 == 0) kh = 4;
-    else if (d->K % 160 == 0) kh = 5;
-    else if (mode >= 2) kh = d->K <= 96 ? 3 : (d->K <= 128 ? 4 : 5);      // (tests: K tails)
-    if (!kh) return 0;
-    if (mode < 2 && (d->C < 64 || (int64_t)d->N * d->P * d->Q < 20000)) return 0;
-    return kh;
-}
-
-void wpf_fill(WppArgs& a, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int split_len) {
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.slab = slab;
-    a.xbytes = (unsigned)((int64_t)d->N * d->H * d->W * d->ldx * 2);
-    a.dybytes = (unsigned)((int64_t)d->N * d->P * d->Q * d->ldy * 2);
-    a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
-    a.K = d->K; a.S = d->R * d->S; a.ldy = d->ldy;
-    a.M = d->N * d->P * d->Q; a.RSC = d->R * d->S * d->C;
-    a.split_len = split_len;
-    const bool tr = d->S == 1 && d->R > 1;
-    int IA, IB;
-    if (tr) { IA = d->W; IB = d->H; a.OA = d->Q; a.OB = d->P; a.pa = d->pad_w; a.pb = d->pad_h;
-              a.sa = d->ldx; a.sb = d->W * d->ldx; a.dsa = d->ldy; a.dsb = d->Q * d->ldy; }
-    else { IA = d->H; IB = d->W; a.OA = d->P; a.OB = d->Q; a.pa = d->pad_h; a.pb = d->pad_w;
-           a.sa = d->W * d->ldx; a.sb = d->ldx; a.dsa = d->Q * d->ldy; a.dsb = d->ldy; }
-    a.simg = d->H * d->W * d->ldx; a.dsimg = d->P * d->Q * d->ldy;
-    a.MajP = IA + a.pa; a.MinP = IB + a.pb; a.ImgP = a.MajP * a.MinP;
-    a.N = d->N; a.G = d->N * a.ImgP;
-    a.fImg = make_fastdiv((uint32_t)a.ImgP); a.fLine = make_fastdiv((uint32_t)a.MinP);
-    a.tilesJ = cdiv(d->C, 64);
-    a.tiles = cdiv(d->K, 32 * kh) * a.tilesJ;
-}
-int64_t pps_slots(const ifcbk_conv_desc* d) {
-    const bool tr = d->S == 1 && d->R > 1;
-    return (int64_t)d->N * ((tr ? d->W + d->pad_w : d->H + d->pad_h)) * ((tr ? d->H + d->pad_h : d->W + d->pad_w));
-}
-
 }  // namespace
 
 // Plan: does the wide-tile kernel serve this weight gradient, with which channel tile (kh = 4, 5, 6: 128 / 160 / 192 output
@@ -605,22 +362,6 @@ int64_t pps_slots(const ifcbk_conv_desc* d) {
 bool ifcbk_wgrad_pp_plan(const ifcbk_conv_desc* d, int* kh_out, int* nsplit_out, int* split_len_out) {
     const int mode = wpp_mode();
     if (mode <= 0 || d->dtype != IFCBK_BF16 || d->Cw != d->C) return false;
-    if (const int fk = pps_kh(d)) {
-        // the flat-slot form: one block per CU, splits over slot ranges
-        const int tiles = cdiv(d->K, 32 * fk) * cdiv(d->C, 64);
-        const int cus = ifcbk_num_cus();
-        const int64_t G = pps_slots(d), steps = (G + 63) / 64;
-        int64_t ns = cus / tiles;
-        const int64_t maxsplit = steps / 8 > 0 ? steps / 8 : 1;
-        if (ns > maxsplit) ns = maxsplit;
-        if (ns < 1) ns = 1;
-        const int64_t len = ((steps + ns - 1) / ns) * 64;
-        ns = (G + len - 1) / len;
-        *kh_out = KH_PPS + fk;
-        *nsplit_out = (int)ns;
-        *split_len_out = (int)len;
-        return true;
-    }
     const int64_t M = (int64_t)d->N * d->P * d->Q;
     const int RSC = d->R * d->S * d->C;
     if (RSC % 4) return false;
@@ -671,16 +412,6 @@ static void wpp_fill(WppArgs& a, const ifcbk_conv_desc* d, const void* x, const 
 int ifcbk_wgrad_pp_launch(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* dy, float* slab, int kh, int nsplit,
                           int split_len, hipStream_t st) {
     WppArgs a;
-    if (kh > KH_PPS) {
-        wpf_fill(a, d, x, dy, slab, kh - KH_PPS, split_len);
-        const dim3 grid((unsigned)(a.tiles * nsplit)), block(512);
-        if (kh == KH_PPS + 3) hipLaunchKernelGGL((conv_wgrad_pps<3, 7>), grid, block, 0, st, a);
-        else if (kh == KH_PPS + 4) hipLaunchKernelGGL((conv_wgrad_pps<4, 7>), grid, block, 0, st, a);
-        else if (kh == KH_PPS + 5) hipLaunchKernelGGL((conv_wgrad_pps<5, 7>), grid, block, 0, st, a);
-        else IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_pps: kh=%d", kh);
-        IFCBK_LAUNCH_CHECK(ctx, "conv_wgrad_pps");
-        return 0;
-    }
     wpp_fill(a, d, x, dy, slab, kh, split_len);
     const dim3 grid((unsigned)(a.tiles * nsplit)), block(512);
     // (DM = 1 -- the pieces issued from inside the MFMA cluster -- was 5-10 % slower everywhere and is no longer instantiated)
@@ -701,7 +432,6 @@ constexpr int KH_FLAT = 16;      // pseudo channel tile: the member is a flat-sl
 int group_member_kh(const ifcbk_conv_desc* d) {
     if (d->dtype != IFCBK_BF16 || d->Cw != d->C) return 0;
     if (ifcbk_wgrad_flat_member(d)) return KH_FLAT;
-    if (const int fk = pps_kh(d)) return KH_PPS + fk;
     const int RSC = d->R * d->S * d->C;
     if (RSC % 4 || d->K % 8 || d->C % 8 || d->ldx % 8 || d->ldy % 8) return 0;
     if ((int64_t)d->N * d->P * d->Q * d->ldy * 2 >= (1ll << 31) || (int64_t)d->N * d->H * d->W * d->ldx * 2 >= (1ll << 31)) return 0;
@@ -729,19 +459,13 @@ bool group_plan(int n, const ifcbk_conv_desc* ds, GroupPlan* gp) {
     const int mode = wpp_mode();
     if (mode <= 0) return false;
     int kh = 0;
-    int64_t steps[WPP_MAXG], total[WPP_MAXG];
+    int64_t steps[WPP_MAXG];
     for (int i = 0; i < n; ++i) {
         const int k = group_member_kh(&ds[i]);
         if (!k || (kh && k != kh)) return false;
         kh = k;
-        if (kh > KH_PPS) {
-            gp->tiles[i] = cdiv(ds[i].K, 32 * (kh - KH_PPS)) * cdiv(ds[i].C, 64);
-            total[i] = pps_slots(&ds[i]);                // the reduction runs over flat slots
-        } else {
-            gp->tiles[i] = cdiv(ds[i].K, 32 * kh) * cdiv(ds[i].R * ds[i].S * ds[i].C, 256);
-            total[i] = (int64_t)ds[i].N * ds[i].P * ds[i].Q;
-        }
-        steps[i] = (total[i] + 63) / 64;      // (conv_wgrad_flat members: a lower bound of their slot steps; only the acceptance test below reads it)
+        gp->tiles[i] = cdiv(ds[i].K, 32 * kh) * cdiv(ds[i].R * ds[i].S * ds[i].C, 256);
+        steps[i] = ((int64_t)ds[i].N * ds[i].P * ds[i].Q + 63) / 64;      // (flat-slot members: a lower bound of their slot steps; only the acceptance test below reads it)
     }
     const int cus = ifcbk_num_cus();
     if (kh == KH_FLAT) {
@@ -769,7 +493,8 @@ bool group_plan(int n, const ifcbk_conv_desc* ds, GroupPlan* gp) {
     for (int i = 0; i < n; ++i) {
         int64_t ns = (steps[i] + L - 1) / L;
         const int64_t len = ((steps[i] + ns - 1) / ns) * 64;
-        ns = (total[i] + len - 1) / len;
+        const int64_t M = (int64_t)ds[i].N * ds[i].P * ds[i].Q;
+        ns = (M + len - 1) / len;
         gp->nsplit[i] = (int)ns;
         gp->split_len[i] = (int)len;
         gp->slab_off[i] = off;
@@ -822,8 +547,7 @@ extern "C" int ifcbk_conv2d_wgrad_group(ifcbk_ctx* ctx, int n, const ifcbk_conv_
     for (int i = 0; i < n; ++i) {
         if ((uintptr_t)dws[i] % 16) IFCBK_FAIL(ctx, IFCBK_EINVAL, "wgrad_group: dW of member %d is not 16-byte aligned", i);
         float* slab = (float*)((char*)ctx->ws + gp.slab_off[i]);
-        if (gp.kh > KH_PPS) wpf_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh - KH_PPS, gp.split_len[i]);
-        else if (!flat) wpp_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh, gp.split_len[i]);
+        if (!flat) wpp_fill(g.a[i], &descs[i], xs[i], dys[i], slab, gp.kh, gp.split_len[i]);
         g.blk0[i] = blk;
         blk += gp.tiles[i] * gp.nsplit[i];
         r.slab[i] = slab; r.dw[i] = dws[i]; r.nsplit[i] = gp.nsplit[i];
@@ -835,9 +559,6 @@ extern "C" int ifcbk_conv2d_wgrad_group(ifcbk_ctx* ctx, int n, const ifcbk_conv_
     g.n = n; r.n = n; r.accumulate = accumulate;
     const dim3 grid((unsigned)blk), block(512);
     if (flat) { if (int e = ifcbk_wgrad_flat_group_launch(ctx, n, descs, xs, dys, gp.nsplit, gp.split_len, gp.slab_off, st)) return e; }
-    else if (gp.kh == KH_PPS + 3) hipLaunchKernelGGL((conv_wgrad_ppsg<3, 7>), grid, block, 0, st, g);
-    else if (gp.kh == KH_PPS + 4) hipLaunchKernelGGL((conv_wgrad_ppsg<4, 7>), grid, block, 0, st, g);
-    else if (gp.kh == KH_PPS + 5) hipLaunchKernelGGL((conv_wgrad_ppsg<5, 7>), grid, block, 0, st, g);
     else if (gp.kh == 4) hipLaunchKernelGGL((conv_wgrad_ppg<4>), grid, block, 0, st, g);
     else if (gp.kh == 5) hipLaunchKernelGGL((conv_wgrad_ppg<5>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((conv_wgrad_ppg<6>), grid, block, 0, st, g);

@@ -574,8 +574,7 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_CONV_WGRAD: case IFCBK_OP_CONV_WGRAD_SEG: {
             int mt = 0, cols = 0;
             ifcbk_conv_wgrad_shape(&o->u.conv, &mt, &cols);
-            if (mt < -32) snprintf(name, cap, "conv_wgrad_pps<%d, 7>", -mt - 32);      // the flat-slot form of the 7-tap layers
-            else if (mt < 0) {
+            if (mt < 0) {
                 snprintf(name, cap, "conv_wgrad_pp<%d, 0>", -mt);          // the name rocprofv3 lists: <KH, DM>
             }
             else if (o->u.conv.dtype == IFCBK_F32) snprintf(name, cap, "conv_wgrad_f32<%d>", mt);
@@ -594,7 +593,6 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
                 for (int k = 0; k < n; ++k) ds[k] = it[k].d;
                 if (ifcbk_conv2d_wgrad_group_info(n, ds, &kh, nullptr, nullptr) == IFCBK_OK) {
                     if (kh == 16) snprintf(name, cap, "conv_wgrad_flatg");
-                    else if (kh > 32) snprintf(name, cap, "conv_wgrad_ppsg<%d, 7>", kh - 32);
                     else snprintf(name, cap, "conv_wgrad_ppg<%d>", kh);
                 }
             }

@@ -12,10 +12,6 @@ from ifcb_classifier_amd import _lib
 from ifcb_classifier_amd._lib import ConvDesc
 
 LAYERS = {
-    '6e_1x7':   (256, 192, 17, 17, 192, 1, 7, 0, 3),
-    '6e_7x1':   (256, 192, 17, 17, 192, 7, 1, 3, 0),
-    '6c_1x7':   (256, 160, 17, 17, 160, 1, 7, 0, 3),
-    '6b_7x1':   (256, 128, 17, 17, 128, 7, 1, 3, 0),
     '5x_3x3a':  (256, 64, 35, 35, 96, 3, 3, 1, 1),
     '5x_3x3b':  (256, 96, 35, 35, 96, 3, 3, 1, 1),
     '5x_5x5':   (256, 48, 35, 35, 64, 5, 5, 2, 2),
@@ -62,7 +58,6 @@ for name, (N, Cc, H, W, K, R, S, ph, pw) in LAYERS.items():
     outs = {}
     for sw in ('0', '1'):
         os.environ['IFCBK_WGRAD_FLAT'] = sw
-        os.environ['IFCBK_WGRAD_PPS'] = sw
         ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
         dw = torch.full((K, R, S, Cc), float('nan'), device='cuda')
         run = lambda dw=dw: ctx.call('ifcbk_conv2d_wgrad', C.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), 0, st)
@@ -73,7 +68,6 @@ for name, (N, Cc, H, W, K, R, S, ph, pw) in LAYERS.items():
     for r in range(reps):
         for sw in ('0', '1'):
             os.environ['IFCBK_WGRAD_FLAT'] = sw
-            os.environ['IFCBK_WGRAD_PPS'] = sw
             ms[sw].append(timeit(outs[sw][1]))
     m0, m1 = min(ms['0']), min(ms['1'])
     print('%-9s old %-24s %7.3f ms %5.0f TF | new %-18s %7.3f ms %5.0f TF x%.2f | err old %.1e new %.1e'
@@ -112,35 +106,3 @@ if need:
     fl = sum(members[k][3] for k in grp)
     print('Inception-A block: 3 single launches %.3f ms %.0f TF | one group %.3f ms %.0f TF x%.2f'
           % (min(a), fl / min(a) / 1e9, min(b), fl / min(b) / 1e9, min(a) / min(b)))
-
-
-# Mixed_6e: its six 7-tap layers as one group, old form (conv_wgrad_ppg<6>) vs flat-slot form (conv_wgrad_ppsg<3, 7>)
-grp = ['6e_1x7', '6e_7x1'] * 3
-n = len(grp)
-descs = (ConvDesc * n)(*[members[k][0] for k in grp])
-xs, dys, dws = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
-keep = []
-for i, k in enumerate(grp):
-    d, x, dy, _ = members[k]
-    dw = torch.zeros(d.K, d.R, d.S, d.C, device='cuda')
-    xs[i], dys[i], dws[i] = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
-    keep.append(dw)
-res = {}
-for sw in ('0', '1'):
-    os.environ['IFCBK_WGRAD_PPS'] = sw
-    need = ctx.lib.ifcbk_conv2d_wgrad_group_workspace(n, descs)
-    ctx.reserve(max(need, 1 << 30))
-    kh = C.c_int(0)
-    ctx.lib.ifcbk_conv2d_wgrad_group_info(n, descs, C.byref(kh), None, None)
-    fn = lambda: ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 0, st)
-    fn(); torch.cuda.synchronize()
-    res[sw] = (kh.value, need, keep[0].clone())
-ms = {'0': [], '1': []}
-for r in range(reps):
-    for sw in ('0', '1'):
-        os.environ['IFCBK_WGRAD_PPS'] = sw
-        ms[sw].append(timeit(lambda: ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 0, st)))
-fl = sum(members[k][3] for k in grp)
-print('Mixed_6e group of six: old (kh %d, ws %.0f MB) %.3f ms %.0f TF | flat-slot (kh %d, ws %.0f MB) %.3f ms %.0f TF x%.2f | rel %.1e'
-      % (res['0'][0], res['0'][1] / 1e6, min(ms['0']), fl / min(ms['0']) / 1e9, res['1'][0], res['1'][1] / 1e6, min(ms['1']),
-         fl / min(ms['1']) / 1e9, min(ms['0']) / min(ms['1']), rel(res['1'][2], res['0'][2])))

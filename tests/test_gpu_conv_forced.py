@@ -41,7 +41,7 @@ def _kname(ctx, d, kind, flags=0, residual=False):
 def forced(monkeypatch):
     def set_(**kw):
         for k in ('IFCBK_CONV_BIG', 'IFCBK_CONV_BIG_MT', 'IFCBK_CONV_BIG_TN', 'IFCBK_WGRAD_PP', 'IFCBK_WGRAD_PP_KH',
-                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_CONV_SLAB', 'IFCBK_WGRAD_FLAT', 'IFCBK_WGRAD_PPS'):
+                  'IFCBK_CONV_FLAT', 'IFCBK_CONV_PP3', 'IFCBK_CONV_PP3_GRID', 'IFCBK_CONV_SLAB', 'IFCBK_WGRAD_FLAT'):
             monkeypatch.delenv(k, raising=False)
         for k, v in kw.items():
             monkeypatch.setenv(k, str(v))
@@ -278,7 +278,7 @@ WGRAD = [
 @pytest.mark.parametrize('case,kh,lx,ly', WGRAD)
 def test_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
     from ifcb_classifier_amd import _lib
-    forced(IFCBK_WGRAD_PP=2, IFCBK_WGRAD_PP_KH=kh, IFCBK_WGRAD_PPS=0, IFCBK_WGRAD_FLAT=0)
+    forced(IFCBK_WGRAD_PP=2, IFCBK_WGRAD_PP_KH=kh)
     N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
     x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 21, lx, ly)
     d = _desc(case, P, Q, LDX, LDY)
@@ -299,83 +299,6 @@ def test_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
     ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 1, st)      # accumulate
     torch.cuda.synchronize()
     assert _rel(dw.cpu(), 2 * rdw) < 1e-4
-
-
-# the flat-slot form of the wide-tile weight gradient (conv_wgrad_pps, round 5): 7-tap filters along either axis, every channel tile
-# (96 / 128 / 160), chunk tails (160 = 64 + 64 + 32, 72 = 64 + 8), K tails, slices, slot counts off the 64-slot step
-WPPS = [
-    ((3, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3), 3, 0, 0),          # inception's 1x7: two K tiles of 96 x three chunks
-    ((3, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0), 3, 0, 0),          # ... its 7x1: column-major slots
-    ((2, 160, 17, 17, 160, 7, 1, 1, 1, 3, 0), 5, 16, 24),        # one 160-channel tile, chunk tail 32, slices
-    ((2, 128, 13, 19, 128, 1, 7, 1, 1, 0, 3), 4, 8, 0),          # 128-channel tile
-    ((4, 72, 12, 23, 104, 1, 7, 1, 1, 0, 3), 4, 0, 8),           # K tail (104 of 128), chunk tail 8
-    ((5, 64, 21, 11, 88, 7, 1, 1, 1, 3, 0), 3, 0, 0),            # K tail (88 of 96), one chunk, 21-pixel lines
-]
-
-
-@pytest.mark.parametrize('case,kh,lx,ly', WPPS)
-def test_flat_slot_wide_tile_weight_gradient_forced(ctx, forced, case, kh, lx, ly):
-    from ifcb_classifier_amd import _lib
-    forced(IFCBK_WGRAD_PPS=2, IFCBK_WGRAD_PP=2, IFCBK_WGRAD_FLAT=0)
-    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
-    x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 61, lx, ly)
-    d = _desc(case, P, Q, LDX, LDY)
-    assert _kname(ctx, d, _lib.OP_CONV_WGRAD) == 'conv_wgrad_pps<%d, 7>' % kh, _kname(ctx, d, _lib.OP_CONV_WGRAD)
-    st = _lib.cur_stream()
-    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-    F.conv2d(xr, wr, None, (sh, sw), (ph, pw)).backward(dy)
-    rdw = wr.grad.permute(0, 2, 3, 1)
-    xp, _ = _slice(xb, lx // 2, Cc)
-    dyp, _ = _slice(dyb, ly // 2, K)
-    ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
-    outs = []
-    for rep in range(2):
-        dw = torch.full((K, R, S, Cc), float('nan'), device='cuda')
-        ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 0, st)
-        torch.cuda.synchronize()
-        outs.append(dw.cpu())
-    assert torch.equal(outs[0], outs[1])
-    assert _rel(outs[0], rdw) < 1e-4
-    err = (outs[0] - rdw).abs().max().item()
-    assert err <= 2e-5 * max(1.0, rdw.abs().max().item()) * (N * P * Q) ** 0.5, err
-    ctx.call('ifcbk_conv2d_wgrad', C.byref(d), xp, dyp, _lib.ptr(dw), 1, st)      # accumulate
-    torch.cuda.synchronize()
-    assert _rel(dw.cpu(), 2 * rdw) < 1e-4
-
-
-def test_flat_slot_wide_tile_weight_gradients_as_one_group(ctx, forced):
-    """four 7-tap layers (1x7 and 7x1, 192 -> 192) as ONE grid + one reduce against their single launches"""
-    from ifcb_classifier_amd import _lib
-    forced(IFCBK_WGRAD_PPS=2, IFCBK_WGRAD_PP=2, IFCBK_WGRAD_FLAT=0)
-    cases = [(5, 192, 17, 17, 192, 1, 7, 1, 1, 0, 3), (5, 192, 17, 17, 192, 7, 1, 1, 1, 3, 0)] * 2
-    n = len(cases)
-    st = _lib.cur_stream()
-    descs = (_lib.ConvDesc * n)()
-    xs, dys, dws, keep, single = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), [], []
-    for i, case in enumerate(cases):
-        N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
-        x, w, dy, xb, dyb, wk, wT, P, Q, LDX, LDY = _tensors(case, 70 + i)
-        d = _desc(case, P, Q, LDX, LDY)
-        descs[i] = d
-        assert ctx.lib.ifcbk_conv2d_wgrad_group_member_kh(C.byref(d)) == 35
-        ctx.reserve(ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
-        dw1 = torch.full((K, R, S, Cc), float('nan'), device='cuda')
-        ctx.call('ifcbk_conv2d_wgrad', C.byref(d), _lib.ptr(xb), _lib.ptr(dyb), _lib.ptr(dw1), 0, st)
-        torch.cuda.synchronize()
-        single.append(dw1.cpu())
-        dwg = torch.full((K, R, S, Cc), float('nan'), device='cuda')
-        xs[i], dys[i], dws[i] = xb.data_ptr(), dyb.data_ptr(), dwg.data_ptr()
-        keep.append((xb, dyb, dwg))
-    need = ctx.lib.ifcbk_conv2d_wgrad_group_workspace(n, descs)
-    assert need > 0
-    ctx.reserve(need)
-    kh = C.c_int(0)
-    assert ctx.lib.ifcbk_conv2d_wgrad_group_info(n, descs, C.byref(kh), None, None) == 0 and kh.value == 35
-    op = _lib.Op()
-    ctx.call('ifcbk_conv2d_wgrad_group', n, descs, xs, dys, dws, 0, st)
-    torch.cuda.synchronize()
-    for i in range(n):
-        assert _rel(keep[i][2].cpu(), single[i]) < 1e-6      # (other split counts: the same products in another split order)
 
 
 # the flat-slot weight gradient (conv_wgrad_flat.hip, round 5): one filter row per block, the x slab shared by the row's taps.  3x3
@@ -423,8 +346,8 @@ def test_flat_slot_weight_gradient_forced(ctx, forced, case, lx, ly):
 
 
 def test_flat_slot_weight_gradients_as_one_group(ctx, forced):
-    """three layers of one block (5x5 48 -> 64, 3x3 64 -> 96, 3x3 96 -> 96) as ONE grid + one reduce, against their single launches
-    (the split counts differ: same products, another split order -- equal to fp32 rounding)"""
+    """three layers of one block (5x5 48 -> 64, 3x3 64 -> 96, 3x3 96 -> 96) as ONE grid + one reduce: equal, bit for bit, to their
+    single launches (same per-block sums, same reduce order); ifcbk_op_kernel names the grouped kernel"""
     from ifcb_classifier_amd import _lib
     forced(IFCBK_WGRAD_FLAT=2, IFCBK_WGRAD_PP=2)
     cases = [(6, 48, 15, 15, 64, 5, 5, 1, 1, 2, 2), (6, 64, 15, 15, 96, 3, 3, 1, 1, 1, 1), (6, 96, 15, 15, 96, 3, 3, 1, 1, 1, 1)]
