@@ -896,6 +896,10 @@ class Engine:
         def _carve(nelem):
             """a d(raw) buffer out of ONE pooled allocation per engine (78 tensors of an inception plan: one hipMalloc instead of 78,
             not zero-filled -- BatchNorm backward writes every element before anything reads it)"""
+            if not self.wgrad_lane:
+                # (without a weight-gradient lane only the members of grouped launches keep a buffer of their own: a handful of
+                # tensors -- a pool sized for EVERY conv, 4.6 GB at batch 256, would be mostly unused)
+                return torch.empty(nelem, dtype=self.tdtype, device=self.dev)
             if getattr(self, '_draw_pool', None) is None:
                 tot = 0
                 for m in self.convs:
