@@ -14,14 +14,24 @@ with open(sys.argv[1]) as f:
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-# a step ends with the Adam kernel
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[2]]
+# a step ends with its LAST Adam launch (the optimizer runs in IFCBK_OPT_BUCKETS launches per step): the one that ends last
+# among those started before the next step's first forward kernel (the stem conv)
+adam_all = [i for i, r in enumerate(rows) if 'adam_kernel' in r[2]]
+stems = [r[0] for r in rows if 'stem_u8_fwd' in r[2]]
+if stems:
+    adam = []
+    for a, b in zip(stems, stems[1:] + [1 << 62]):
+        mine = [i for i in adam_all if a <= rows[i][0] < b]
+        if mine:
+            adam.append(max(mine, key=lambda i: rows[i][1]))
+    adam = sorted(set(adam))
+else:
+    adam = adam_all
 if len(adam) < nsteps + 1:
     raise SystemExit('not enough steps in the trace')
 lo, hi = adam[-nsteps - 1] + 1, adam[-1] + 1
 sel = rows[lo:hi]
 t0, t1 = rows[adam[-nsteps - 1]][1], max(r[1] for r in sel)
-
 
 def short(n):
     n = re.sub(r'^void ', '', n).replace('(anonymous namespace)::', '')
