@@ -27,14 +27,14 @@ OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4        # include/ifcb
  OP_WEIGHT_PACK_MULTI, OP_CONV_WGRAD_SEG, OP_BN_APPLY_MAXPOOL, OP_BN_BWD_MAXPOOL, OP_CONV_DGRAD_BNSTAT,
  OP_BN_BWD_PARTIALS, OP_BN_STATS, OP_AVGPOOL_AFFINE, OP_CONV_FWD_AFFINE_SEG, OP_SGD, OP_CONV_DGRAD_BNSTAT_TAB,
  OP_BIAS_RELU_BWD, OP_DROPOUT, OP_FLATTEN_CHW, OP_STEM_U8_FWD, OP_STEM_U8_WGRAD, OP_CONV_FWD_AFFINE_MAXPOOL,
- OP_STEP_COUNTERS, OP_CONV_WGRAD_GROUP, OP_BN_BWD_SUMS) = range(1, 41)
+ OP_STEP_COUNTERS, OP_CONV_WGRAD_GROUP) = range(1, 40)
 
 OP_NAMES = {1: 'conv_fwd', 2: 'conv_dgrad', 3: 'conv_wgrad', 4: 'weight_pack', 5: 'bn_finalize', 6: 'bn_apply',
             7: 'bn_bwd', 8: 'maxpool_fwd', 9: 'maxpool_bwd', 10: 'avgpool_fwd', 11: 'avgpool_bwd', 12: 'head_fwd',
             13: 'head_bwd', 14: 'softmax_xent', 15: 'softmax', 16: 'adam', 17: 'memset', 18: 'copy2d',
             19: 'dropout_mask', 20: 'conv_fwd_affine', 21: 'weight_pack_multi', 22: 'conv_wgrad', 23: 'bn_apply_maxpool',
             24: 'bn_bwd_maxpool', 25: 'conv_dgrad', 26: 'bn_bwd', 27: 'bn_stats', 28: 'avgpool_fwd', 29: 'conv_fwd_affine', 30: 'sgd', 31: 'conv_dgrad',
-            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine', 38: 'step_counters', 39: 'conv_wgrad', 40: 'bn_bwd'}
+            32: 'bias_relu_bwd', 33: 'dropout', 34: 'flatten_chw', 35: 'conv_fwd', 36: 'conv_wgrad', 37: 'conv_fwd_affine', 38: 'step_counters', 39: 'conv_wgrad'}
 
 
 class ConvDesc(C.Structure):
@@ -62,16 +62,6 @@ class RoiDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('n_img', 'S', 'in_channels', 'out_channels', 'flip_bits_valid', 'dtype')] + \
                [('mean', C.c_float * 3), ('std', C.c_float * 3), ('tin_scale', C.c_float * 3),
                 ('tin_shift', C.c_float * 3)]
-
-
-class BnFin(C.Structure):
-    """ifcbk_bnfin (include/ifcbk.h): the finalize step done by the kernel that produced the partial rows -- a HOST struct the op table
-    points to (the engine keeps it alive)"""
-    _fields_ = [('kind', C.c_int32), ('nseg', C.c_int32), ('seg_end', C.c_int32 * 4),
-                ('gamma', C.c_void_p * 4), ('beta', C.c_void_p * 4), ('running_mean', C.c_void_p * 4), ('running_var', C.c_void_p * 4),
-                ('mean', C.c_void_p), ('invstd', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
-                ('M', C.c_int64), ('eps', C.c_float), ('momentum', C.c_float),
-                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('sums', C.c_void_p), ('accumulate', C.c_int32)]
 
 
 class BsChunk(C.Structure):
@@ -107,7 +97,6 @@ _PROTOS = {
     'ifcbk_ctx_live_graphs': (_i, [_vp]),
     'ifcbk_last_error': (C.c_char_p, [_vp]),
     'ifcbk_conv2d_fwd': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
-    'ifcbk_conv2d_fwd_fin': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, C.POINTER(BnFin), _vp]),
     'ifcbk_conv2d_fwd_affine': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'ifcbk_conv2d_fwd_affine_maxpool_ok': (_i, [C.POINTER(ConvDesc)]),
     'ifcbk_conv2d_fwd_affine_maxpool': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
@@ -131,12 +120,9 @@ _PROTOS = {
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, _vp, _vp]),
     'ifcbk_avgpool3x3_affine': (_i, [_vp, C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp, _vp]),
     'ifcbk_bn_stats_rows': (_i, [C.c_int64]),
-    'ifcbk_bn_bwd_workspace': (C.c_size_t, [C.c_int64, _i]),
     'ifcbk_bn_stats': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _vp]),
     'ifcbk_conv2d_dgrad_bnstat_mblocks': (_i, [C.POINTER(ConvDesc)]),
     'ifcbk_conv2d_dgrad_bnstat': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'ifcbk_conv2d_dgrad_bnstat_fin': (_i, [_vp, C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(BnFin), _vp]),
-    'ifcbk_bn_bwd_sums': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'ifcbk_bn_bwd_partials': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i,
                                    _vp]),
     'ifcbk_bn_bwd_partials_ld': (_i, [_vp, C.POINTER(BnDesc), _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,

@@ -2,17 +2,18 @@
 // Every access is a 16-byte chunk (8 bf16 or 4 fp32 channels), consecutive lanes on consecutive chunks; all
 // kernels are templated on the storage type T (bf16 performance mode / fp32 parity mode).
 #include "common.h"
-#include "bnfin.h"
 #include <stdlib.h>
 
 namespace {
 
-// timing experiment (never set in the product): IFCBK_EXPERIMENT_NOFINALIZE=<n> skips every finalize launch after the first n
-// (the statistics of the first steps stay in place, so the data keep their scale)
+// timing experiment (never set in the product; scripts/README.md): IFCBK_EXPERIMENT_NOFINALIZE=<n> skips every finalize launch
+// after the first n -- the statistics of the first steps stay in place, so the data keep their scale --, with
+// IFCBK_EXPERIMENT_EMPTYFINALIZE=1 an empty one-wave kernel takes its place.  What the 192 finalize launches of an inception_v3
+// step cost: DESIGN 5.10
 __global__ void experiment_empty_kernel(float* p) { if (p && threadIdx.x == 1000) p[0] = 0.f; }
-bool experiment_skip_finalize(hipStream_t st = nullptr) {
+bool experiment_skip_finalize(hipStream_t st) {
     static const char* e = getenv("IFCBK_EXPERIMENT_NOFINALIZE");
-    static const char* k = getenv("IFCBK_EXPERIMENT_EMPTYFINALIZE");     // ... but launch an empty one-wave kernel in its place
+    static const char* k = getenv("IFCBK_EXPERIMENT_EMPTYFINALIZE");
     static long seen = 0;
     if (!e) return false;
     const bool skip = ++seen > atol(e);
@@ -72,62 +73,6 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
         if (rmean) {
             rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
             rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)(var * unbias);
-        }
-    }
-}
-
-// The same reduction for up to 64 * U partial rows, shaped for LATENCY (this kernel sits between every training conv and its
-// bn_apply, 96 times per inception_v3 step, and the step pays ~6 us for each: DESIGN 5.10): every thread requests all of its rows and
-// the writing threads their parameters before anything is used -- one memory round trip instead of three --, the 64 row groups
-// are folded by two wave shuffles and one 16-entry pass instead of a 64-entry serial pass.  Fixed order: rows rg, rg + 64, ... per
-// thread; row groups 4w .. 4w+3 inside wave w by xor 16, 32; waves 0 .. 15 in order.
-template <int U, int NT>
-__global__ __launch_bounds__(NT) void bn_finalize_fast_kernel(const float* part, int mblocks, int ldp, int C, double invM,
-                                                                 double unbias, const float* gamma, const float* beta,
-                                                                 float* rmean, float* rvar, float* mean_o, float* invstd_o,
-                                                                 float* scale, float* shift, float eps, float momentum) {
-    constexpr int NG = NT / 16, NWV = NT / 64;      // row groups, waves
-    __shared__ double sw[NWV][2][16];
-    const int t = threadIdx.x, c = t & 15, rg = t >> 4, wave = t >> 6;
-    const int ch = blockIdx.x * 16 + c;
-    const bool writer = t < 16 && ch < C;
-    float g = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
-    if (writer) {
-        g = gamma[ch];
-        bt = beta[ch];
-        if (rmean) { rm = rmean[ch]; rv = rvar[ch]; }
-    }
-    float v1[U], v2[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int row = rg + NG * u;
-        const bool ok = ch < C && row < mblocks;
-        v1[u] = ok ? part[((size_t)row * 2 + 0) * ldp + ch] : 0.f;
-        v2[u] = ok ? part[((size_t)row * 2 + 1) * ldp + ch] : 0.f;
-    }
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { a += (double)v1[u]; b += (double)v2[u]; }
-    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-    if ((t & 63) < 16) { sw[wave][0][c] = a; sw[wave][1][c] = b; }
-    __syncthreads();
-    if (writer) {
-        double sa = 0.0, sb = 0.0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) { sa += sw[w][0][c]; sb += sw[w][1][c]; }
-        const double mean = sa * invM;
-        double var = sb * invM - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = g * invstd;
-        mean_o[ch] = (float)mean;
-        invstd_o[ch] = invstd;
-        scale[ch] = sc;
-        shift[ch] = bt - (float)mean * sc;
-        if (rmean) {
-            rmean[ch] = (1.f - momentum) * rm + momentum * (float)mean;
-            rvar[ch] = (1.f - momentum) * rv + momentum * (float)(var * unbias);
         }
     }
 }
@@ -368,7 +313,7 @@ template <class T, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_pool2x2_kernel(const T* x, int ldx, const T* dp, const float* mean,
                                                                      const float* invstd, const float* scale, const float* shift,
                                                                      float* part, int C, PoolGather pg, int HB, int WB,
-                                                                     uint32_t nblk, fastdiv_t fHBWB, fastdiv_t fWB, BnFin fin) {
+                                                                     uint32_t nblk, fastdiv_t fHBWB, fastdiv_t fWB) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;
     constexpr int TILE = 256;                    // 2x2 blocks per partial row (1024 pixels)
@@ -438,11 +383,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool2x2_kernel(const T* x, 
         int ch = blockIdx.y * CG + nn;
         if (ch < C) {
             float s_ = red[0][which][nn] + red[1][which][nn] + red[2][which][nn] + red[3][which][nn];
-            if (fin.cnt) bnfin_store(&part[((size_t)blockIdx.x * 2 + which) * C + ch], s_);
-            else part[((size_t)blockIdx.x * 2 + which) * C + ch] = s_;
+            part[((size_t)blockIdx.x * 2 + which) * C + ch] = s_;
         }
     }
-    bnfin_arrive<256>(fin, (int)blockIdx.x, 1, (int)gridDim.y, t);
 }
 
 template <class T, int MASK>
@@ -516,8 +459,7 @@ static inline int bwd_rows(int64_t M, int cgroups) {
 template <class T, int MASK, bool POOLED>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx, const T* y, int ldy, const T* dy, int lddy,
                                                              const float* mean, const float* invstd, const float* scale,
-                                                             const float* shift, float* part, int64_t M, int C, PoolGather pg, int rows,
-                                                             BnFin fin) {
+                                                             const float* shift, float* part, int64_t M, int C, PoolGather pg, int rows) {
     constexpr int E = Chunk<T>::N;
     constexpr int CG = 8 * E;                    // channels per block
     __shared__ float red[4][2][CG];
@@ -574,11 +516,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* x, int ldx,
         int ch = blockIdx.y * CG + n;
         if (ch < C) {
             float s = red[0][which][n] + red[1][which][n] + red[2][which][n] + red[3][which][n];
-            if (fin.cnt) bnfin_store(&part[((size_t)blockIdx.x * 2 + which) * C + ch], s);
-            else part[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
+            part[((size_t)blockIdx.x * 2 + which) * C + ch] = s;
         }
     }
-    bnfin_arrive<256>(fin, (int)blockIdx.x, 1, (int)gridDim.y, t);      // the finalize pass, by the last block of a row group
 }
 
 // pass 2: sum the row-tile partials (fixed order) -> dbeta, dgamma (+ temp copy used by pass 3)
@@ -623,43 +563,6 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
         tmp[C + ch] = (float)sg;    // dgamma
         dbeta[ch] = accumulate ? dbeta[ch] + (float)sa : (float)sa;
         dgamma[ch] = accumulate ? dgamma[ch] + (float)sg : (float)sg;
-    }
-}
-
-// latency-shaped twin of the pass below for up to 64 * U row tiles (see bn_finalize_fast_kernel)
-template <int U, int NT>
-__global__ __launch_bounds__(NT) void bn_bwd_finalize_fast_kernel(const float* part, int ntiles, int C, float* dgamma, float* dbeta,
-                                                                     float* tmp, int accumulate, int ldp) {
-    constexpr int NG = NT / 16, NWV = NT / 64;      // row groups, waves
-    __shared__ double sw[NWV][2][16];
-    const int t = threadIdx.x, c = t & 15, rg = t >> 4, wave = t >> 6;
-    const int ch = blockIdx.x * 16 + c;
-    const bool writer = t < 16 && ch < C;
-    float ob = 0.f, og = 0.f;
-    if (writer && accumulate) { ob = dbeta[ch]; og = dgamma[ch]; }
-    float v1[U], v2[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int row = rg + NG * u;
-        const bool ok = ch < C && row < ntiles;
-        v1[u] = ok ? part[((size_t)row * 2 + 0) * ldp + ch] : 0.f;
-        v2[u] = ok ? part[((size_t)row * 2 + 1) * ldp + ch] : 0.f;
-    }
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { a += (double)v1[u]; b += (double)v2[u]; }
-    a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-    a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-    if ((t & 63) < 16) { sw[wave][0][c] = a; sw[wave][1][c] = b; }
-    __syncthreads();
-    if (writer) {
-        double sa = 0.0, sg = 0.0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) { sa += sw[w][0][c]; sg += sw[w][1][c]; }
-        tmp[ch] = (float)sa;        // dbeta
-        tmp[C + ch] = (float)sg;    // dgamma
-        dbeta[ch] = accumulate ? ob + (float)sa : (float)sa;
-        dgamma[ch] = accumulate ? og + (float)sg : (float)sg;
     }
 }
 
@@ -746,44 +649,6 @@ int apply_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const float* 
     return 0;
 }
 
-// which finalize kernel: the latency-shaped one where a thread holds all its rows (<= 1536 rows), IFCBK_BN_FIN_FAST=0: never
-static int fin_fast() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("IFCBK_BN_FIN_FAST"); on = e ? atoi(e) : 1; }
-    return on;
-}
-static void launch_bwd_finalize(const float* part, int ntiles, int C, float* dgamma, float* dbeta, float* tmp, int accumulate, int ldp,
-                                hipStream_t st) {
-    const dim3 g(cdiv(C, 16)), b(1024), bs(256);
-    const int ff = fin_fast();
-    if (ff == 2 && ntiles <= 256) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<16, 256>), g, bs, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else if (ff == 2 && ntiles <= 512) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<32, 256>), g, bs, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else if (ff && ntiles <= 256) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<4, 1024>), g, b, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else if (ff && ntiles <= 512) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<8, 1024>), g, b, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else if (ff && ntiles <= 1024) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<16, 1024>), g, b, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else if (ff && ntiles <= 1536) hipLaunchKernelGGL((bn_bwd_finalize_fast_kernel<24, 1024>), g, b, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-    else hipLaunchKernelGGL(bn_bwd_finalize_kernel, g, b, 0, st, part, ntiles, C, dgamma, dbeta, tmp, accumulate, ldp);
-}
-
-// The in-kernel finalize of bn_bwd's reduction pass (bnfin.h): counters = the launching lane's block, group sums = the lane's
-// workspace behind the partial rows and the (dbeta, dgamma) copy.
-static BnFin bwd_fin(ifcbk_ctx* ctx, float* part, int rows, int C, float* tmp, float* dgamma, float* dbeta, int accumulate) {
-    BnFin f = {};
-    // Off by default (IFCBK_BN_FIN bit 1): the reduction pass runs ~3,000 blocks of a few microseconds, and the arrive (wait for
-    // the stores, barrier, one atomic round trip) lengthens every one of them -- measured 0.2 ms per step SLOWER than the finalize
-    // kernel it replaces.  The conv producers (one long block per CU) are where it pays.
-    if (!bnfin_switch(1) || !ctx->fin || bnfin_groups(rows) > BNFIN_MAX_GROUPS) return f;
-    const size_t off = (((size_t)rows * 2 * C + 2 * C) * sizeof(float) + 15) & ~(size_t)15;
-    if (off + bnfin_gsum_bytes(rows, C) > ctx->ws_bytes || (char*)part != (char*)ctx->ws) return f;
-    f.cnt = ctx->fin;
-    f.gsum = (double*)((char*)ctx->ws + off);
-    f.part = part;
-    f.o0 = dgamma; f.o1 = dbeta; f.o2 = tmp;
-    f.kind = 1;
-    f.rows = rows; f.GR = bnfin_group_rows(rows); f.ngroups = bnfin_groups(rows); f.C = C; f.ldp = C; f.accumulate = accumulate;
-    return f;
-}
-
 template <class T>
 int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, const void* dy, int lddy,
           const float* gamma, const float* mean, const float* invstd, void* dx, int lddx, void* dres, int lddres,
@@ -807,8 +672,6 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
     // ReLU mask: recomputed from x when the caller hands over bn_apply's scale/shift and there is no residual
     const int mask = !d->relu ? 0 : ((scale && shift && !dres) ? 2 : 1);
     if (mask == 1 && !yy) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: y is required for the ReLU mask");
-    // the reduction pass sums its own partial rows (bnfin.h) unless the rows come from another kernel (part_in)
-    const BnFin fin = part_in ? BnFin{} : bwd_fin(ctx, part, ntiles, C, tmp, dgamma, dbeta, param_accumulate);
     if (pool && pg.ph == 0 && pg.pw == 0) {
         if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
         const int HB = (pg.H + 1) / 2, WB = (pg.W + 1) / 2;
@@ -818,13 +681,12 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         const int nt2 = cdiv(nblk, 256);
         if (((size_t)nt2 * 2 * C + 2 * C) * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_maxpool: workspace");
         float* tmp2 = part + (size_t)nt2 * 2 * C;
-        const BnFin fin2 = bwd_fin(ctx, part, nt2, C, tmp2, dgamma, dbeta, param_accumulate);
         const fastdiv_t fHBWB = make_fastdiv(HB * WB), fWB = make_fastdiv(WB), fc2 = make_fastdiv(C / E);
         dim3 g2(nt2, cdiv(C, CG));
-        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 2>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB, fin2);
-        else hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 0>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB, fin2);
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 2>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
+        else hipLaunchKernelGGL((bn_bwd_reduce_pool2x2_kernel<T, 0>), g2, dim3(256), 0, st, xx, d->ldx, dd, mean, invstd, scale, shift, part, C, pg, HB, WB, (uint32_t)nblk, fHBWB, fWB);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce_pool2x2");
-        if (!fin2.cnt && !experiment_skip_finalize(st)) launch_bwd_finalize((const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate, C, st);
+        if (!experiment_skip_finalize(st)) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, (const float*)part, nt2, C, dgamma, dbeta, tmp2, param_accumulate, C);
         IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
         const float invM2 = (float)(1.0 / (double)M);
         const size_t shm2 = (size_t)5 * C * sizeof(float);
@@ -838,21 +700,17 @@ int bwd_t(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* y, 
         if (mask != 2 || dres) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: ReLU layer without residual, scale/shift required");
         part = const_cast<float*>(part_in);
         ntiles = ntiles_in;
-        if (ntiles_in < 0) {
-            tmp = part;          // ifcbk_bn_bwd_sums: part_in IS the final (dbeta, dgamma) pair, the parameter gradients are done
-        } else {
-            tmp = (float*)ctx->ws;
-            if ((size_t)2 * C * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_partials: workspace");
-        }
+        tmp = (float*)ctx->ws;
+        if ((size_t)2 * C * sizeof(float) > ctx->ws_bytes) IFCBK_FAIL(ctx, IFCBK_ENOMEM, "bn_bwd_partials: workspace");
     } else if (pool) {
         if (mask == 1) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_maxpool: needs scale/shift (the activation is not stored)");
-        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows, fin);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows, fin);
-    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows, fin);
-    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows, fin);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows, fin);
+        if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, true>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    } else if (mask == 2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 0, false>), g1, dim3(256), 0, st, xx, d->ldx, yy, d->ldy, dd, lddy, mean, invstd, scale, shift, part, M, C, pg, rows);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_reduce");
-    if (!fin.cnt && !(part_in && ntiles_in < 0) && !experiment_skip_finalize(st)) launch_bwd_finalize((const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C, st);
+    if (!experiment_skip_finalize(st)) hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, (const float*)part, ntiles, C, dgamma, dbeta, tmp, param_accumulate, (part_in && part_ld_in > 0) ? part_ld_in : C);
     IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
     const int64_t total = M * (C / E);
     if (total >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd: tensor too large");
@@ -900,30 +758,15 @@ extern "C" int ifcbk_bn_finalize_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, cons
             mblocks = nchunk;
             ldp = d->C;
         }
-        const dim3 fg(cdiv(d->C, 16)), fb(1024);
-#define IFCBK_FIN_ARGS part, mblocks, ldp, d->C, 1.0 / M, unbias, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, d->eps, d->momentum
-        if (experiment_skip_finalize(st)) {}
-        else if (fin_fast() == 2 && mblocks <= 256) hipLaunchKernelGGL((bn_finalize_fast_kernel<16, 256>), fg, dim3(256), 0, st, IFCBK_FIN_ARGS);
-        else if (fin_fast() == 2 && mblocks <= 512) hipLaunchKernelGGL((bn_finalize_fast_kernel<32, 256>), fg, dim3(256), 0, st, IFCBK_FIN_ARGS);
-        else if (fin_fast() && mblocks <= 256) hipLaunchKernelGGL((bn_finalize_fast_kernel<4, 1024>), fg, fb, 0, st, IFCBK_FIN_ARGS);
-        else if (fin_fast() && mblocks <= 512) hipLaunchKernelGGL((bn_finalize_fast_kernel<8, 1024>), fg, fb, 0, st, IFCBK_FIN_ARGS);
-        else if (fin_fast() && mblocks <= 1024) hipLaunchKernelGGL((bn_finalize_fast_kernel<16, 1024>), fg, fb, 0, st, IFCBK_FIN_ARGS);
-        else if (fin_fast() && mblocks <= 1536) hipLaunchKernelGGL((bn_finalize_fast_kernel<24, 1024>), fg, fb, 0, st, IFCBK_FIN_ARGS);
-        else hipLaunchKernelGGL(bn_finalize_kernel, fg, fb, 0, st, IFCBK_FIN_ARGS);
-#undef IFCBK_FIN_ARGS
+        if (!experiment_skip_finalize(st)) hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(d->C, 16)), dim3(1024), 0, st, part, mblocks, ldp, d->C, 1.0 / M,
+                           unbias, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, d->eps,
+                           d->momentum);
     } else {
         hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(d->C, 256)), dim3(256), 0, st, d->C, gamma, beta,
                            (const float*)running_mean, (const float*)running_var, scale, shift, d->eps);
     }
     IFCBK_LAUNCH_CHECK(ctx, "bn_finalize");
     return 0;
-}
-
-extern "C" size_t ifcbk_bn_bwd_workspace(int64_t M, int C) {
-    if (M <= 0 || C <= 0) return 0;
-    const int rows = cdiv(M, 256);              // (bwd_rows() never cuts finer)
-    const size_t base = (((size_t)rows * 2 * C + 2 * C) * sizeof(float) + 15) & ~(size_t)15;
-    return base + bnfin_gsum_bytes(rows, C);
 }
 
 extern "C" int ifcbk_bn_stats_rows(int64_t M) { return (int)((M + STAT_ROWS - 1) / STAT_ROWS); }
@@ -1068,27 +911,6 @@ extern "C" int ifcbk_bn_bwd_partials_ld(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, 
         return bwd_t<bf16_t>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, dgamma, dbeta,
                              param_accumulate, scale, shift, (hipStream_t)stream, nullptr, part, ntiles, part_ld);
     IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_partials: bad dtype");
-}
-
-extern "C" int ifcbk_bn_bwd_sums(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* dy, int lddy, const float* gamma,
-                                 const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
-                                 void* dx, int lddx, void* stream) {
-    if (!d || !sums) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_sums: bad args");
-    if (d->dtype == IFCBK_F32)
-        return bwd_t<float>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, nullptr, nullptr, 0, scale, shift,
-                            (hipStream_t)stream, nullptr, sums, -1, 0);
-    if (d->dtype == IFCBK_BF16)
-        return bwd_t<bf16_t>(ctx, d, x, nullptr, dy, lddy, gamma, mean, invstd, dx, lddx, nullptr, 0, 0, nullptr, nullptr, 0, scale, shift,
-                             (hipStream_t)stream, nullptr, sums, -1, 0);
-    IFCBK_FAIL(ctx, IFCBK_EINVAL, "bn_bwd_sums: bad dtype");
-}
-
-// the finalize kernel behind a producer that has no in-kernel form (conv_igemm.hip's fallback for ifcbk_bnfin kind 1)
-int ifcbk_bn_bwd_finalize_rows(ifcbk_ctx* ctx, const float* part, int rows, int C, int ldp, float* dgamma, float* dbeta, float* sums,
-                               int accumulate, hipStream_t st) {
-    launch_bwd_finalize(part, rows, C, dgamma, dbeta, sums, accumulate, ldp, st);
-    IFCBK_LAUNCH_CHECK(ctx, "bn_bwd_finalize");
-    return 0;
 }
 
 extern "C" int ifcbk_bn_bwd_partials(ifcbk_ctx* ctx, const ifcbk_bn_desc* d, const void* x, const void* dy, int lddy,

@@ -23,8 +23,6 @@ struct ifcbk_ctx {
     hipEvent_t* cev;     // ordering events of stream captures: one per edge, never reused inside a capture
     int n_cev, cev_next, capturing;
     void* zeros;         // 4 KiB of zeros: source address of padded / out-of-range LDS-DMA chunks
-    unsigned* fin;       // in-kernel BatchNorm finalize (bnfin.h): the counter block of the lane that is launching (1024 counters,
-    unsigned* fin_base;  // zero between launches); IFCBK_MAX_LANES blocks
     hipEvent_t* ev;      // profiling events for ifcbk_run_program
     int n_ev;
     hipEvent_t* slot_ev[256];   // ifcbk_run_program_ev: (start, stop) per op
@@ -160,9 +158,6 @@ bool ifcbk_conv_rows_pool_ok(int dtype, int cin, int cout, int R, int S, int str
 int ifcbk_conv_rows_pool_launch(ifcbk_ctx* ctx, int N, int H, int W, int ldx, int P, int Q, int pad_h, int pad_w, const void* x,
                                 const void* w, void* y, int ldy, const float* scale, const float* shift, int relu, hipStream_t st);
 int ifcbk_num_cus();
-// bn.hip: the finalize kernel of the backward sums, for a producer without the in-kernel form (bnfin.h)
-int ifcbk_bn_bwd_finalize_rows(ifcbk_ctx* ctx, const float* part, int rows, int C, int ldp, float* dgamma, float* dbeta, float* sums,
-                               int accumulate, hipStream_t st);
 // conv_big.hip: wide-tile (256/320 pixels x 128..256 channels) ping-pong kernel; plan = does it serve this GEMM, and with which tile
 bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt, int* tn);
 // persistent wide-tile kernel (conv_pp3.hip): epi 0 = raw store (+ statistics), 1 = eval affine (+ReLU)

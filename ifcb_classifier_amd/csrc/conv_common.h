@@ -2,7 +2,6 @@
 // helpers and the common epilogue (C tile in LDS -> coalesced 16-byte row stores + fused statistics / affine / accumulate).
 #pragma once
 #include "common.h"
-#include "bnfin.h"
 
 namespace {
 
@@ -46,9 +45,6 @@ struct ConvArgs {
     int tr;
     fastdiv_t fP;
     int dbg;                                // timing-only diagnostics of conv_big.hip (0 in production)
-    // the partial rows in `part` are summed by the kernel itself (bnfin.h): forward batch statistics -> mean / invstd / scale /
-    // shift / running statistics, or the fused input gradient's backward sums -> dbeta / dgamma.  fin.cnt == nullptr: off
-    BnFin fin;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -296,11 +292,9 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, T* sC, fl
                     float s = 0.f;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) s += sRed[(w * 2 + which) * BN + n];
-                    if (a.fin.cnt) bnfin_store(&a.part[((size_t)mtile * 2 + which) * a.K + n0 + n], s);
-                    else a.part[((size_t)mtile * 2 + which) * a.K + n0 + n] = s;
+                    a.part[((size_t)mtile * 2 + which) * a.K + n0 + n] = s;
                 }
             }
-            bnfin_arrive<NTHREADS>(a.fin, mtile, 1, (a.K + BN - 1) / BN, t);       // (a.part and a.fin are block-uniform)
         }
     }
 }

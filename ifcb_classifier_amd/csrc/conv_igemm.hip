@@ -565,11 +565,8 @@ bool pp3_ok(const ConvArgs& a) {
     return big_ok(a) && !a.seg_n && !a.bs_raw && !a.bs_tab && !a.accumulate && !a.ep_res && (a.ep_scale == nullptr || a.part == nullptr);
 }
 
-// fin_done (when a.fin.cnt is set): does the kernel this dispatch picks sum its partial rows itself (conv_epilogue_store does:
-// conv_igemm, conv_pp2, conv_slab)?  false -> the caller launches the finalize kernel behind it
-int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st, bool* fin_done = nullptr) {
+int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st) {
     const bool f32 = dtype == IFCBK_F32;
-    if (fin_done) *fin_done = false;
     if (!a.wKg && !(a.ish | a.isw) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && !a.accumulate && !a.ep_res && a.PQ > 0) {
         // stride-1 3x3 / 5x5 layers over 48..96 channels: the flat-image kernel (conv_flat.hip)
         const int N = a.M / a.PQ;
@@ -581,19 +578,14 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st, bool* fin_done =
     // shape only: whatever the batch, such a layer always takes this kernel, and an eval batch equals its parts bit for bit
     if (big_ok(a) && a.ostr_h == 1 && a.ostr_w == 1 && !a.seg_n && !a.bs_tab && a.PQ > 0) {
         const int N = a.M / a.PQ;
-        if (ifcbk_conv_slab_plan(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0) {
-            if (fin_done) *fin_done = true;
+        if (ifcbk_conv_slab_plan(dtype, N, a.H, a.W, a.C, a.K, a.R, a.S, -a.base_h, -a.base_w, a.P, a.Q) > 0)
             return ifcbk_conv_slab_launch(ctx, &a, N, st);
-        }
     }
     // grids of several tiles per CU whose epilogue is a raw store (+ statistics) or the eval affine: the persistent kernel
     if (pp3_ok(a) && ifcbk_conv_pp3_plan(dtype, a.M, a.K, a.Kg, a.ep_scale ? 1 : 0)) return ifcbk_conv_pp3_launch(ctx, &a, st);
     {
         int bmt = 0, btn = 0;
-        if (big_ok(a) && ifcbk_conv_big_plan(dtype, a.M, a.K, a.Kg, &bmt, &btn)) {
-            if (fin_done) *fin_done = true;
-            return ifcbk_conv_big_launch(ctx, &a, bmt, btn, st);
-        }
+        if (big_ok(a) && ifcbk_conv_big_plan(dtype, a.M, a.K, a.Kg, &bmt, &btn)) return ifcbk_conv_big_launch(ctx, &a, bmt, btn, st);
     }
     int wm = f32 ? 2 : pick_wm(a.M, a.K);
     int nt = pick_nt(a.K, f32 ? 4 : (wm == 4 ? 5 : 6), a.M, 64 * wm);
@@ -611,7 +603,6 @@ int run(ifcbk_ctx* ctx, ConvArgs& a, int dtype, hipStream_t st, bool* fin_done =
         IFCBK_LAUNCH_CHECK(ctx, "conv_ws");
         return 0;
     }
-    if (fin_done) *fin_done = true;
     if (f32) {
         switch (nt) {
             case 1: launch<float, 1, 2, 2>(a, st); break;
@@ -674,42 +665,7 @@ extern "C" int ifcbk_conv2d_fwd_mblocks(const ifcbk_conv_desc* d) {
 struct FwdSegs { int n, end[4], ld[4], aff[4]; void* y[4]; };
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
-                         const FwdSegs* seg = nullptr, const ifcbk_bnfin* fin = nullptr);
-
-// the finalize kernel per segment, behind a forward kernel that did not sum its rows itself
-static int fwd_finalize_classic(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const float* part, int rows, const ifcbk_bnfin* f, void* stream) {
-    for (int q = 0; q < f->nseg; ++q) {
-        const int c0 = q ? f->seg_end[q - 1] : 0, cn = f->seg_end[q] - c0;
-        if (!f->gamma[q] || cn <= 0) continue;
-        ifcbk_bn_desc b = {};
-        b.M = (int32_t)f->M; b.C = cn; b.ldx = b.ldy = cn; b.relu = 0; b.dtype = d->dtype; b.eps = f->eps; b.momentum = f->momentum;
-        if (int e = ifcbk_bn_finalize_ld(ctx, &b, part + c0, rows, d->K, f->gamma[q], f->beta[q], f->running_mean[q], f->running_var[q],
-                                         f->mean + c0, f->invstd + c0, f->scale + c0, f->shift + c0, stream))
-            return e;
-    }
-    return 0;
-}
-static int check_fin(ifcbk_ctx* ctx, const ifcbk_bnfin* f, int kind, int K) {
-    if (f->kind != kind) IFCBK_FAIL(ctx, IFCBK_EINVAL, "bnfin: kind %d, expected %d", f->kind, kind);
-    if (kind == 0) {
-        if (f->nseg < 1 || f->nseg > 4 || f->seg_end[f->nseg - 1] != K || f->M <= 0 || !f->mean || !f->invstd || !f->scale || !f->shift)
-            IFCBK_FAIL(ctx, IFCBK_EINVAL, "bnfin: forward form needs 1..4 segments ending at K=%d, M and the four outputs", K);
-        for (int q = 0; q < f->nseg; ++q)
-            if ((f->gamma[q] && !f->beta[q]) || (!f->running_mean[q]) != (!f->running_var[q]) || f->seg_end[q] <= (q ? f->seg_end[q - 1] : 0))
-                IFCBK_FAIL(ctx, IFCBK_EINVAL, "bnfin: segment %d", q);
-    } else if (!f->dgamma || !f->dbeta || !f->sums) {
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "bnfin: backward form needs dgamma, dbeta, sums");
-    }
-    return 0;
-}
-
-extern "C" int ifcbk_conv2d_fwd_fin(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
-                                    const ifcbk_bnfin* fin, void* stream) {
-    if (!fin) return conv_fwd_impl(ctx, d, x, w, y, bn_part, nullptr, nullptr, nullptr, 0, 0, stream);
-    if (!d || !bn_part) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_fwd_fin: the partial rows are required");
-    if (int e = check_fin(ctx, fin, 0, d->K)) return e;
-    return conv_fwd_impl(ctx, d, x, w, y, bn_part, nullptr, nullptr, nullptr, 0, 0, stream, nullptr, fin);
-}
+                         const FwdSegs* seg = nullptr);
 
 extern "C" int ifcbk_conv2d_fwd_affine_segments(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, int nseg,
                                                 void* const* ys, const int32_t* ldys, const int32_t* ksegs, const int32_t* affine,
@@ -777,7 +733,7 @@ extern "C" int ifcbk_conv2d_fwd_affine_maxpool(ifcbk_ctx* ctx, const ifcbk_conv_
 
 static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x, const void* w, void* y, float* bn_part,
                          const float* scale, const float* shift, const void* residual, int ldr, int relu, void* stream,
-                         const FwdSegs* seg, const ifcbk_bnfin* fin) {
+                         const FwdSegs* seg) {
     if (d && (d->dtype == IFCBK_BF16 || d->dtype == IFCBK_F32) && d->N > 1) {
         // The kernels address a tensor through a 32-bit buffer descriptor (2 GiB).  A forward WITHOUT batch statistics (eval /
         // affine epilogues: every image on its own) whose tensors exceed the window runs as several launches over image groups
@@ -808,15 +764,11 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
         }
     }
     if (int e = check_desc(ctx, d)) return e;
-    if (fwd_rows(d) && !residual && !seg) {
-        if (int e = ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,
-                                           bn_part, scale, shift, relu, (hipStream_t)stream))
-            return e;
-        return fin ? fwd_finalize_classic(ctx, d, bn_part, ifcbk_conv2d_fwd_mblocks(d), fin, stream) : 0;
-    }
+    if (fwd_rows(d) && !residual && !seg)
+        return ifcbk_conv_rows_launch(ctx, d->C, d->K, d->N, d->H, d->W, d->ldx, d->P, d->Q, d->ldy, d->pad_h, d->pad_w, x, w, y,
+                                      bn_part, scale, shift, relu, (hipStream_t)stream);
     ConvArgs a;
     a.dbg = 0; a.tr = 0; a.fP = make_fastdiv(1);
-    a.fin = BnFin{};
     a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_ldr = ldr; a.ep_relu = relu;
     a.x = x; a.w = w; a.y = y; a.part = bn_part;
     a.bs_raw = nullptr; a.bs_mean = a.bs_invstd = a.bs_scale = a.bs_shift = nullptr; a.bs_ld = 0; a.bs_tab = nullptr;
@@ -835,12 +787,7 @@ static int conv_fwd_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* x
     a.wKg = 0; a.wSfull = 0; a.w_rbase = 0; a.w_sbase = 0; a.oH = 0; a.oW = 0; a.o_a = 0; a.o_b = 0;
     a.M = d->N * d->P * d->Q; a.Kg = d->R * d->S * d->C; a.accumulate = 0; a.PQ = d->P * d->Q;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
-    if (!fin) return run(ctx, a, d->dtype, (hipStream_t)stream);
-    const int rows = ifcbk_conv2d_fwd_mblocks(d);
-    a.fin = bnfin_make(ctx, fin, bn_part, rows, d->K, d->K);
-    bool done = false;
-    if (int e = run(ctx, a, d->dtype, (hipStream_t)stream, &done)) return e;
-    return (done && a.fin.cnt) ? 0 : fwd_finalize_classic(ctx, d, bn_part, rows, fin, stream);
+    return run(ctx, a, d->dtype, (hipStream_t)stream);
 }
 
 struct BnStatArgs {
@@ -858,7 +805,7 @@ static bool dgrad_bnstat_ok(const ifcbk_conv_desc* d) {
 }
 
 static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx, int accumulate,
-                      const BnStatArgs* bs, void* stream, const ifcbk_bnfin* fin = nullptr);
+                      const BnStatArgs* bs, void* stream);
 
 extern "C" int ifcbk_conv2d_dgrad(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
                                   int accumulate, void* stream) {
@@ -887,19 +834,6 @@ extern "C" int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx* ctx, const ifcbk_conv_desc* 
     return dgrad_impl(ctx, d, dy, wT, dx, 0, &bs, stream);
 }
 
-extern "C" int ifcbk_conv2d_dgrad_bnstat_fin(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
-                                             const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
-                                             const float* prev_scale, const float* prev_shift, float* part, const ifcbk_bnfin* fin,
-                                             void* stream) {
-    if (!fin) return ifcbk_conv2d_dgrad_bnstat(ctx, d, dy, wT, dx, prev_raw, prev_ld, prev_mean, prev_invstd, prev_scale, prev_shift, part, stream);
-    if (!d || !dgrad_bnstat_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_dgrad_bnstat_fin: stride-1 implicit-GEMM input gradients only");
-    if (!prev_raw || !prev_mean || !prev_invstd || !prev_scale || !prev_shift || !part)
-        IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv2d_dgrad_bnstat_fin: null operand");
-    if (int e = check_fin(ctx, fin, 1, d->C)) return e;
-    BnStatArgs bs = {prev_raw, prev_ld, prev_mean, prev_invstd, prev_scale, prev_shift, part, nullptr};
-    return dgrad_impl(ctx, d, dy, wT, dx, 0, &bs, stream, fin);
-}
-
 extern "C" int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx,
                                                const ifcbk_bs_chunk* table, float* part, void* stream) {
     if (!d || !dgrad_bnstat_ok(d)) IFCBK_FAIL(ctx, IFCBK_EUNSUPPORTED, "conv2d_dgrad_bnstat_table: stride-1 implicit-GEMM input gradients only");
@@ -910,7 +844,7 @@ extern "C" int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx* ctx, const ifcbk_conv_
 }
 
 static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, const void* wT, void* dx, int accumulate,
-                      const BnStatArgs* bs, void* stream, const ifcbk_bnfin* fin) {
+                      const BnStatArgs* bs, void* stream) {
     if (int e = check_desc(ctx, d, true)) return e;
     // the input gradient of a 3x3/stride-1 conv is a 3x3/stride-1 conv of dy with the flipped filter (wT), padding 2 - pad
     if (!bs && !accumulate && ifcbk_conv_rows_ok(d->dtype, d->K, d->C, d->R, d->S, d->stride_h, d->stride_w, 2 - d->pad_h, 2 - d->pad_w, d->W))
@@ -919,7 +853,6 @@ static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, 
     // gather over dy [N,P,Q,K] producing dx [N,H,W,C]: roles of (H,W,C) and (P,Q,K) swap
     ConvArgs a;
     a.dbg = 0; a.tr = 0; a.fP = make_fastdiv(1);
-    a.fin = BnFin{};
     a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_ldr = 0; a.ep_relu = 0;
     a.x = dy; a.w = wT; a.y = dx; a.part = bs ? bs->part : nullptr;
     a.seg_n = 0;
@@ -962,12 +895,5 @@ static int dgrad_impl(ifcbk_ctx* ctx, const ifcbk_conv_desc* d, const void* dy, 
     a.ish = d->stride_h == 2 ? 1 : 0; a.isw = d->stride_w == 2 ? 1 : 0;
     a.M = d->N * d->H * d->W; a.Kg = d->R * d->S * d->K; a.PQ = d->H * d->W;
     a.fPQ = make_fastdiv(a.PQ); a.fQ = make_fastdiv(a.Q);
-    if (!fin || !bs) return run(ctx, a, d->dtype, (hipStream_t)stream);
-    // (the fused form is stride 1: the parity-class loop above never sees it)
-    const int rows = ifcbk_conv2d_dgrad_bnstat_mblocks(d);
-    a.fin = bnfin_make(ctx, fin, bs->part, rows, d->C, d->C);
-    bool done = false;
-    if (int e = run(ctx, a, d->dtype, (hipStream_t)stream, &done)) return e;
-    if (done && a.fin.cnt) return 0;
-    return ifcbk_bn_bwd_finalize_rows(ctx, bs->part, rows, d->C, d->C, fin->dgamma, fin->dbeta, fin->sums, fin->accumulate, (hipStream_t)stream);
+    return run(ctx, a, d->dtype, (hipStream_t)stream);
 }

@@ -63,9 +63,6 @@ extern "C" int ifcbk_ctx_create(int device, ifcbk_ctx** out) {
     e = hipSetDevice(device);
     if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc(&c->zeros, 4096); }
     if (e == hipSuccess) { what = "hipMemset"; e = hipMemset(c->zeros, 0, 4096); }
-    if (e == hipSuccess) { what = "hipMalloc"; e = hipMalloc((void**)&c->fin_base, (size_t)IFCBK_MAX_LANES * 4096); }
-    if (e == hipSuccess) { what = "hipMemset"; e = hipMemset(c->fin_base, 0, (size_t)IFCBK_MAX_LANES * 4096); }
-    c->fin = c->fin_base;
     if (e != hipSuccess) {
         snprintf(g_create_err, sizeof(g_create_err), "ifcbk_ctx_create(device=%d): %s: %s", device, what, hipGetErrorString(e));
         free(c);
@@ -84,7 +81,6 @@ extern "C" int ifcbk_ctx_destroy(ifcbk_ctx* c) {
     while (c->graphs) graph_free(c, c->graphs);
     if (c->ws_base) (void)hipFree(c->ws_base);
     if (c->zeros) (void)hipFree(c->zeros);
-    if (c->fin_base) (void)hipFree(c->fin_base);
     for (int l = 1; l < IFCBK_MAX_LANES; ++l) {
         if (c->lane_st[l]) (void)hipStreamDestroy(c->lane_st[l]);
         if (c->cap_st[l]) (void)hipStreamDestroy(c->cap_st[l]);
@@ -138,7 +134,7 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
     void* const* p = o->p;
     const int acc = o->flags & 1, pacc = (o->flags >> 1) & 1;
     switch (o->kind) {
-        case IFCBK_OP_CONV_FWD: return ifcbk_conv2d_fwd_fin(c, &o->u.conv, p[0], p[1], p[2], (float*)p[3], (const ifcbk_bnfin*)p[4], st);
+        case IFCBK_OP_CONV_FWD: return ifcbk_conv2d_fwd(c, &o->u.conv, p[0], p[1], p[2], (float*)p[3], st);
         case IFCBK_OP_CONV_FWD_AFFINE:
             return ifcbk_conv2d_fwd_affine(c, &o->u.conv, p[0], p[1], p[2], (const float*)p[3], (const float*)p[4], p[5],
                                            (int)o->i[0], (o->flags >> 2) & 1, st);
@@ -172,15 +168,12 @@ static int run_one(ifcbk_ctx* c, const ifcbk_op* o, void* st) {
                                 (const float*)p[5], p[6], (int)o->i[1], p[7], (int)o->i[2], acc | (((o->flags >> 3) & 1) << 1), (float*)p[8], (float*)p[9],
                                 pacc, (const float*)p[10], (const float*)p[11], st);
         case IFCBK_OP_CONV_DGRAD_BNSTAT:
-            return ifcbk_conv2d_dgrad_bnstat_fin(c, &o->u.conv, p[0], p[1], p[2], p[3], (int)o->i[0], (const float*)p[4], (const float*)p[5],
-                                                 (const float*)p[6], (const float*)p[7], (float*)p[8], (const ifcbk_bnfin*)p[9], st);
+            return ifcbk_conv2d_dgrad_bnstat(c, &o->u.conv, p[0], p[1], p[2], p[3], (int)o->i[0], (const float*)p[4], (const float*)p[5],
+                                             (const float*)p[6], (const float*)p[7], (float*)p[8], st);
         case IFCBK_OP_BN_BWD_PARTIALS:
             return ifcbk_bn_bwd_partials_ld(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
                                             (const float*)p[5], (const float*)p[6], (const float*)p[7], (int)o->i[1], (int)o->i[3], p[8],
                                             (int)o->i[2], (float*)p[9], (float*)p[10], pacc, st);
-        case IFCBK_OP_BN_BWD_SUMS:
-            return ifcbk_bn_bwd_sums(c, &o->u.bn, p[0], p[1], (int)o->i[0], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                     (const float*)p[5], (const float*)p[6], (const float*)p[7], p[8], (int)o->i[1], st);
         case IFCBK_OP_CONV_DGRAD_BNSTAT_TAB:
             return ifcbk_conv2d_dgrad_bnstat_table(c, &o->u.conv, p[0], p[1], p[2], (const ifcbk_bs_chunk*)p[3], (float*)p[4], st);
         case IFCBK_OP_CONV_FWD_AFFINE_SEG: {
@@ -327,7 +320,6 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
             }
         if (rc) break;
         c->ws = (char*)c->ws_base + (size_t)L * c->ws_bytes;
-        c->fin = c->fin_base + (size_t)L * 1024;
         const bool timed = ev && (!rec || (ops[i].flags & 0x80));      // run_program_ev brackets only ops with flags bit 7
         if (rec) rec[i] = timed;
         if (timed) IFCBK_HIP(c, hipEventRecord(ev[2 * i], st[L]));
@@ -340,7 +332,6 @@ static int run_lanes(ifcbk_ctx* c, const ifcbk_op* ops, int n, hipStream_t s0, h
         if (timed) IFCBK_HIP(c, hipEventRecord(ev[2 * i + 1], st[L]));
     }
     c->ws = c->ws_base;
-    c->fin = c->fin_base;
     for (int l = 1; l < IFCBK_MAX_LANES; ++l)                                // join, also on the error path
         if (used >> l & 1) (void)lane_order(c, s0, st[l]);
     return rc;
@@ -613,7 +604,6 @@ extern "C" int ifcbk_op_kernel(const ifcbk_op* o, char* name, size_t cap) {
         case IFCBK_OP_BN_APPLY: snprintf(name, cap, "bn_apply_kernel"); break;
         case IFCBK_OP_BN_BWD: snprintf(name, cap, "bn_bwd"); break;
         case IFCBK_OP_BN_BWD_PARTIALS: snprintf(name, cap, "bn_bwd(partials)"); break;
-        case IFCBK_OP_BN_BWD_SUMS: snprintf(name, cap, "bn_bwd(sums)"); break;
         case IFCBK_OP_BN_APPLY_MAXPOOL: snprintf(name, cap, "bn_apply_maxpool_kernel"); break;
         case IFCBK_OP_BN_BWD_MAXPOOL: snprintf(name, cap, "bn_bwd(maxpool)"); break;
         case IFCBK_OP_BN_FINALIZE: snprintf(name, cap, "bn_finalize_kernel"); break;

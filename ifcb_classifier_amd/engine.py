@@ -588,7 +588,7 @@ class Engine:
             d = self._conv_desc(n, Nt)
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(d)))
             M = Nt * n.P * n.Q
-            ws = max(ws, self.ctx.lib.ifcbk_bn_bwd_workspace(M, n.K))
+            ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         for g in self.groups:
             ws = max(ws, self.ctx.lib.ifcbk_conv2d_wgrad_workspace(C.byref(self._group_desc(g, Nt))))
         for n in self.plains:
@@ -596,7 +596,7 @@ class Engine:
                      self.ctx.lib.ifcbk_bias_relu_bwd_workspace(Nt * n.P * n.Q, n.K))
         for n in self.bnrs:
             M = Nt * n.x.H * n.x.W
-            ws = max(ws, self.ctx.lib.ifcbk_bn_bwd_workspace(M, n.K))
+            ws = max(ws, (((M + 255) // 256) * 2 * n.K + 2 * n.K) * 4)
         if self.stem_u8 is not None:
             ws = max(ws, self.ctx.lib.ifcbk_stem_u8_wgrad_workspace(C.byref(self._conv_desc(self.stem_u8, Nt))))
         self.ctx.reserve(ws)
@@ -707,39 +707,6 @@ class Engine:
         """a commuted pool branch's unpooled 1x1-conv output: its channel slice of the sibling GEMM's merged tensor"""
         return _vp(n.group.raw, self.esize * n.koff), n.group.Ktot
 
-    def _bnfin_fwd(self, segs, stat_node, M, keep):
-        """ifcbk_bnfin (kind 0) of a training-forward conv: its kernel finalizes the batch statistics itself (csrc/bnfin.h), the op
-        table carries no OP_BN_FINALIZE for it.  segs: [(conv node or None = a segment whose statistics come from elsewhere, channels)]"""
-        f = _lib.BnFin()
-        f.kind, f.nseg = 0, len(segs)
-        end = 0
-        for q, (m, K) in enumerate(segs):
-            end += K
-            f.seg_end[q] = end
-            if m is not None:
-                f.gamma[q] = self._pptr(m.bn_key + '.weight').value
-                f.beta[q] = self._pptr(m.bn_key + '.bias').value
-                f.running_mean[q] = self.bviews[m.bn_key + '.running_mean'].data_ptr()
-                f.running_var[q] = self.bviews[m.bn_key + '.running_var'].data_ptr()
-        f.mean, f.invstd = self._stat(stat_node, 0).value, self._stat(stat_node, 1).value
-        f.scale, f.shift = self._stat(stat_node, 2).value, self._stat(stat_node, 3).value
-        f.M, f.eps, f.momentum = M, stat_node.eps, 0.1
-        keep.append(f)
-        return C.cast(C.pointer(f), C.c_void_p)
-
-    def _bnfin_bwd(self, pn, keep):
-        """ifcbk_bnfin (kind 1) for the fused input gradient that reduces producer pn's BatchNorm-backward sums: the kernel also
-        finalizes them -> (pointer for the op, the (dbeta, dgamma) buffer OP_BN_BWD_SUMS reads)"""
-        f = _lib.BnFin()
-        f.kind = 1
-        sums = torch.zeros(2 * pn.K, dtype=torch.float32, device=self.dev)
-        f.dgamma = self._pptr(pn.bn_key + '.weight', 'G').value
-        f.dbeta = self._pptr(pn.bn_key + '.bias', 'G').value
-        f.sums = sums.data_ptr()
-        f.accumulate = 0
-        keep.extend([f, sums])
-        return C.cast(C.pointer(f), C.c_void_p), sums
-
     def _bs_table(self, grp, gd, readers, fused_pool):
         """per-chunk producer table (ifcbk_bs_chunk) of the block input a sibling GEMM reads, when that GEMM is the input's only
         consumer and every conv that wrote a slice of it is a plain conv -> BN -> ReLU; None otherwise"""
@@ -836,11 +803,6 @@ class Engine:
         fuse_level = int(os.environ.get('IFCBK_FUSE_BNSTAT', '1'))
         fuse_bnstat = fuse_level >= 1
         keep = []             # device tables / buffers the op tables point into
-        # IFCBK_BN_FIN_OPS=1 (experiment, round 5): the kernel that writes BatchNorm partial rows also sums them (csrc/bnfin.h) -- no
-        # OP_BN_FINALIZE behind a training-forward conv, OP_BN_BWD_SUMS instead of OP_BN_BWD_PARTIALS behind a fused input gradient.
-        # Correct (tests/test_gpu_ops.py) but 0.25 ms per step SLOWER than the finalize kernels it removes: the two
-        # hand-overs between blocks cost a coherent store -> atomic -> load chain of ~2 us per hop.  Off by default.
-        fin_fwd = fin_bwd = os.environ.get('IFCBK_BN_FIN_OPS', '0') == '1'
         if fuse_bnstat:
             for cnode in net.nodes:
                 if cnode.kind != 'conv' or cnode.group is not None or cnode.x.buf.is_input or not cnode.x.is_full:
@@ -1082,14 +1044,9 @@ class Engine:
                         # ONE GEMM for all sibling 1x1 convs, then each branch's BN on its channel slice
                         gd = self._group_desc(g, N)
                         gmb = self.ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(gd))
-                        # the GEMM's kernel finalizes the batch statistics of every member but a commuted pool branch (whose
-                        # BatchNorm sees the POOLED tensor) itself: one segment per member (csrc/bnfin.h)
-                        gfin = (self._bnfin_fwd([(None if m.cpool is not None else m, m.K) for m in g.members], g.members[0], M, keep)
-                                if fin_fwd else None)
                         lst.add(_lib.OP_CONV_FWD, '+'.join(m.name for m in g.members),
-                                p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), _vp(g.raw), _vp(self.bn_part[0]), gfin),
-                                conv=gd, lane=0, reads=[ra(g.x)],
-                                writes=[('gr', id(g), 0, g.Ktot), rbp(0)] + ([rst(m) for m in g.members if m.cpool is None] if gfin else []))
+                                p=(self._aptr(g.x), _vp(self.Wsh, self.esize * g.w_off), _vp(g.raw), _vp(self.bn_part[0])),
+                                conv=gd, lane=0, reads=[ra(g.x)], writes=[('gr', id(g), 0, g.Ktot), rbp(0)])
                         for m in g.members:
                             mbk = m.bn_key
                             mraw, mld = self._raw_ptr(m)
@@ -1115,12 +1072,11 @@ class Engine:
                                 continue
                             # (one finalize per member, not per group: with all 29 member finalizes of the training forward REMOVED
                             # -- timing only -- the step gains 0.15-0.22 ms; merging them into 11 launches could recover part of that)
-                            if gfin is None:
-                                lst.add(_lib.OP_BN_FINALIZE, m.name,
-                                        p=(_vp(self.bn_part[0], 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
-                                           _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
-                                           self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
-                                        i=(gmb, g.Ktot), bn=mbnd, lane=lane_fwd[m], reads=[rbp(0)], writes=[rst(m)])
+                            lst.add(_lib.OP_BN_FINALIZE, m.name,
+                                    p=(_vp(self.bn_part[0], 4 * m.koff), self._pptr(mbk + '.weight'), self._pptr(mbk + '.bias'),
+                                       _vp(self.bviews[mbk + '.running_mean']), _vp(self.bviews[mbk + '.running_var']),
+                                       self._stat(m, 0), self._stat(m, 1), self._stat(m, 2), self._stat(m, 3)),
+                                    i=(gmb, g.Ktot), bn=mbnd, lane=lane_fwd[m], reads=[rbp(0)], writes=[rst(m)])
                             lst.add(_lib.OP_BN_APPLY, m.name,
                                     p=(mraw, self._stat(m, 2), self._stat(m, 3), None, self._aptr(m.y)), i=(0,), bn=mbnd,
                                     lane=lane_fwd[m], reads=[rraw(m), rst(m)], writes=[ra(m.y)])
@@ -1129,10 +1085,9 @@ class Engine:
                         lst.add(_lib.OP_STEM_U8_FWD, n.name, p=(gu8, self._pptr(ckey), gab, raw, _vp(self.bn_part[L]), None, None),
                                 conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
                     else:
-                        nfin = self._bnfin_fwd([(n, n.K)], n, M, keep) if (train and fin_fwd) else None
-                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part[L]) if train else None, nfin),
-                                conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)] + ([rst(n)] if nfin else []))
-                    if train and (u8 or not fin_fwd):
+                        lst.add(_lib.OP_CONV_FWD, n.name, p=(self._aptr(n.x), wk, raw, _vp(self.bn_part[L]) if train else None),
+                                conv=dfw, lane=L, reads=[ra(n.x)], writes=[rraw(n), rbp(L)])
+                    if train:
                         lst.add(_lib.OP_BN_FINALIZE, n.name,
                                 p=(_vp(self.bn_part[L]), self._pptr(bkey + '.weight'), self._pptr(bkey + '.bias'),
                                    _vp(self.bviews[bkey + '.running_mean']), _vp(self.bviews[bkey + '.running_var']),
@@ -1396,14 +1351,6 @@ class Engine:
                                self._stat(n, 0), self._stat(n, 1), self._stat(n, 2), self._stat(n, 3), draw,
                                self._pptr(bkey + '.weight', 'G'), self._pptr(bkey + '.bias', 'G')),
                             i=(1, n.K), pool=ppd, lane=L, reads=[rraw(n), rg(pn.y), ram(pk), rst(n)], writes=rdraw)
-                elif n in bnstat_done and bnstat_done[n][0] is None:
-                    # the consumer's input-gradient kernel left the final (dbeta, dgamma) in `sums` and updated the parameter gradients
-                    _, sums, pres, _ = bnstat_done[n]
-                    bwd.add(_lib.OP_BN_BWD_SUMS, n.name,
-                            p=(rawp, self._aptr(n.y, True), self._pptr(bkey + '.weight'), self._stat(n, 0), self._stat(n, 1),
-                               self._stat(n, 2), self._stat(n, 3), _vp(sums), draw),
-                            i=(n.y.buf.C, n.K if (grp is None or cp) else grp.Ktot), bn=bnd, lane=L,
-                            reads=[rraw(n), rg(n.y), rst(n), pres], writes=rdraw)
                 elif n in bnstat_done:
                     ppart, nrow, pres, pld = bnstat_done[n]
                     bwd.add(_lib.OP_BN_BWD_PARTIALS, n.name,
@@ -1493,17 +1440,6 @@ class Engine:
                         pn = bnstat_of[n]
                         prow, pld = self._raw_ptr(pn)
                         nrow = self.ctx.lib.ifcbk_conv2d_dgrad_bnstat_mblocks(C.byref(dbw))
-                        if fin_bwd:
-                            pfin, sums = self._bnfin_bwd(pn, keep)
-                            rsum = ('bsum', id(pn), 0, 1)
-                            # (p[10], p[11]: the producer's parameter gradients this op finishes -- what the bucket planners read)
-                            bwd.add(_lib.OP_CONV_DGRAD_BNSTAT, n.name,
-                                    p=(draw, wT, self._aptr(n.x, True), prow, self._stat(pn, 0), self._stat(pn, 1),
-                                       self._stat(pn, 2), self._stat(pn, 3), _vp(self.bn_part[L]), pfin,
-                                       self._pptr(pn.bn_key + '.weight', 'G'), self._pptr(pn.bn_key + '.bias', 'G')), i=(pld,), conv=dbw,
-                                    lane=L, reads=rdraw + [rraw(pn), rst(pn)], writes=[rg(n.x), rbp(L), rsum])
-                            bnstat_done[pn] = (None, sums, rsum, 0)
-                            continue
                         bwd.add(_lib.OP_CONV_DGRAD_BNSTAT, n.name,
                                 p=(draw, wT, self._aptr(n.x, True), prow, self._stat(pn, 0), self._stat(pn, 1),
                                    self._stat(pn, 2), self._stat(pn, 3), _vp(self.bn_part[L])), i=(pld,), conv=dbw,
@@ -1711,10 +1647,6 @@ class Engine:
         if o.kind in (_lib.OP_BN_BWD_MAXPOOL, _lib.OP_BN_BWD_PARTIALS):
             g0 = (o.p[9] - base) // 4
             return [g0, (o.p[10] - base) // 4] + self.cbias_after.get(g0, [])
-        if o.kind == _lib.OP_CONV_DGRAD_BNSTAT and o.p[9]:
-            # the fused input gradient whose kernel also finalizes the producer's BatchNorm-backward sums (ifcbk_bnfin kind 1)
-            g0 = (o.p[10] - base) // 4
-            return [g0, (o.p[11] - base) // 4] + self.cbias_after.get(g0, [])
         if o.kind == _lib.OP_HEAD_BWD:
             return [(o.p[4] - base) // 4, (o.p[5] - base) // 4] if o.p[4] else []
         if o.kind == _lib.OP_BIAS_RELU_BWD:

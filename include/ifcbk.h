@@ -166,33 +166,6 @@ IFCBK_API int ifcbk_bn_finalize_ld(ifcbk_ctx*, const ifcbk_bn_desc*, const float
 IFCBK_API int ifcbk_bn_finalize(ifcbk_ctx*, const ifcbk_bn_desc*, const float* part, int mblocks,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* The finalize step done by the kernel that produced the partial rows (csrc/bnfin.h: the last block of a row group sums the group,
- * the last group's block sums the groups and writes the outputs -- fixed summation orders, so the result does not depend on
- * which block comes last).  Handed to ifcbk_conv2d_fwd_fin / ifcbk_conv2d_dgrad_bnstat_fin; those entry points leave the
- * outputs below final in stream order whatever kernel serves the descriptor (one without the in-kernel form is followed by the
- * finalize kernel).  HOST struct, read at launch time.
- *   kind 0  forward batch statistics of the conv output (what ifcbk_bn_finalize computes): mean, invstd, scale, shift [K] over
- *           all channels, and per SEGMENT (fused sibling convs carry one BatchNorm per channel range) gamma / beta / running
- *           statistics indexed from the segment's first channel; gamma[s] == NULL skips segment s (nothing of it is written)
- *   kind 1  backward sums of the producing BatchNorm (what ifcbk_bn_bwd_partials reduces): dbeta, dgamma (+= when accumulate)
- *           and sums[2C] = (dbeta, dgamma) of this batch, which ifcbk_bn_bwd_sums takes                                     */
-typedef struct {
-    int32_t kind, nseg;
-    int32_t seg_end[4];          /* exclusive channel end per segment; seg_end[nseg - 1] = K                       */
-    const float* gamma[4];
-    const float* beta[4];
-    float* running_mean[4];      /* nullable                                                                       */
-    float* running_var[4];
-    float* mean; float* invstd; float* scale; float* shift;
-    int64_t M;                   /* elements per channel                                                           */
-    float eps, momentum;
-    float* dgamma; float* dbeta; float* sums;
-    int32_t accumulate;
-} ifcbk_bnfin;
-/* ifcbk_conv2d_fwd with the batch statistics finalized behind it (fin: kind 0; NULL = ifcbk_conv2d_fwd): replaces the pair
- * ifcbk_conv2d_fwd + ifcbk_bn_finalize(_ld) -- same values up to the summation order of the partial rows (double sums both ways) */
-IFCBK_API int ifcbk_conv2d_fwd_fin(ifcbk_ctx*, const ifcbk_conv_desc*, const void* x, const void* w, void* y, float* bn_part,
-                         const ifcbk_bnfin* fin, void* stream);
 /* y = act(x*scale + shift (+ residual)) */
 IFCBK_API int ifcbk_bn_apply(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const float* scale,
                    const float* shift, const void* residual, int ldr, void* y, void* stream);
@@ -207,15 +180,6 @@ IFCBK_API int ifcbk_bn_bwd(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, cons
                  float* dgamma, float* dbeta, int param_accumulate,
                  const float* scale, const float* shift /* nullable: bn_apply's affine; lets the ReLU mask be
                  recomputed from x (y is then not read) when there is no residual */, void* stream);
-/* bytes of ctx workspace ifcbk_bn_bwd wants for M elements per channel and C channels: the partial rows, the (dbeta, dgamma)
- * copy, and the group sums of the in-kernel finalize (the reduction pass sums its own rows: bnfin.h; with less workspace than
- * this -- but enough for the rows -- it falls back to the separate finalize kernel) */
-IFCBK_API size_t ifcbk_bn_bwd_workspace(int64_t M, int C);
-/* BatchNorm(+ReLU) backward when the two per-channel sums are final already (sums[2C] = dbeta, dgamma of this batch, written by
- * ifcbk_conv2d_dgrad_bnstat_fin, which also updated the parameter gradients): the dx pass alone                              */
-IFCBK_API int ifcbk_bn_bwd_sums(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* dy, int lddy, const float* gamma,
-                      const float* mean, const float* invstd, const float* scale, const float* shift, const float* sums,
-                      void* dx, int lddx, void* stream);
 
 /* ------------------------------------------------------------------ pooling
  * replaces F.max_pool2d / F.avg_pool2d(count_include_pad=True) / adaptive_avg_pool2d in [TV] graphs  */
@@ -366,11 +330,6 @@ IFCBK_API int ifcbk_conv2d_dgrad_bnstat_table(ifcbk_ctx*, const ifcbk_conv_desc*
 IFCBK_API int ifcbk_conv2d_dgrad_bnstat(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
                               const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
                               const float* prev_scale, const float* prev_shift, float* part, void* stream);
-/* ... with the sums finalized by the kernel (ifcbk_bnfin kind 1; part is still written: [mblocks][2][C])                         */
-IFCBK_API int ifcbk_conv2d_dgrad_bnstat_fin(ifcbk_ctx*, const ifcbk_conv_desc*, const void* dy, const void* wT, void* dx,
-                                  const void* prev_raw, int prev_ld, const float* prev_mean, const float* prev_invstd,
-                                  const float* prev_scale, const float* prev_shift, float* part, const ifcbk_bnfin* fin,
-                                  void* stream);
 /* BatchNorm(+ReLU) backward from those partial sums: finalize + dx only                                        */
 IFCBK_API int ifcbk_bn_bwd_partials(ifcbk_ctx*, const ifcbk_bn_desc*, const void* x, const void* dy, int lddy,
                           const float* gamma, const float* mean, const float* invstd, const float* scale,
@@ -422,10 +381,8 @@ enum {
     IFCBK_OP_STEM_U8_WGRAD,  /* p: g, dy, ab, dw; flags bit 0 accumulate                                                           */
     IFCBK_OP_CONV_FWD_AFFINE_MAXPOOL, /* p: x, w, y_pooled, scale, shift; i[0] = ld of y_pooled; flags bit 2 relu                  */
     IFCBK_OP_STEP_COUNTERS,  /* p: num_batches_tracked (i64, nullable), loss_sum (nullable), loss; i[0] = number of BatchNorms      */
-    IFCBK_OP_CONV_WGRAD_GROUP,/* p[0]: HOST array of i[0] ifcbk_wgrad_item entries, kept alive by the caller; p[1..]: the members' dw again
+    IFCBK_OP_CONV_WGRAD_GROUP /* p[0]: HOST array of i[0] ifcbk_wgrad_item entries, kept alive by the caller; p[1..]: the members' dw again
                                * (what the data-parallel bucket planner reads); flags bit 0 accumulate                            */
-    IFCBK_OP_BN_BWD_SUMS      /* p: x, dy, gamma, mean, invstd, scale, shift, sums, dx; i[0] = ld of dy, i[1] = ld of dx (ifcbk_bn_bwd_sums).
-                               * IFCBK_OP_CONV_FWD p[4] / IFCBK_OP_CONV_DGRAD_BNSTAT p[9]: HOST ifcbk_bnfin kept alive by the caller, or NULL */
 };
 typedef struct {
     ifcbk_conv_desc d;
