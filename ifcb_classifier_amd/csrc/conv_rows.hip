@@ -8,6 +8,14 @@
 // taps are MFMA operands read at shifted pixel addresses.  The filter lives in registers (MFMA A operand, loaded once
 // per block), an input fragment feeds COUT/16 MFMAs.  Epilogue as in conv_igemm: output row through LDS, 16-byte stores,
 // BatchNorm statistics of the ROUNDED outputs (one partial row per block), optional eval-BN affine + ReLU.
+//
+// Round 5: the row loop no longer serialises on memory.  It used `__syncthreads()` (which waits for EVERY outstanding memory operation
+// of the wave, so each row waited for the write acknowledgements of the row before it and for the prefetch it had just issued) and
+// plain LDS accesses (in front of which the compiler puts s_waitcnt vmcnt(0) while any LDS-DMA is pending): 6,000 cycles per row and
+// block for 900 cycles of MFMA.  Now: raw s_barrier; inline-asm ds_read_b128 / ds_write_b64 for every LDS access inside the loop; the
+// output row leaves through buffer stores with an out-of-range offset for idle lanes, so that every wave issues exactly KQ (POOL: NI,
+// on the rows that complete a pooled row) store instructions per row and the wait for the next input row at the top of the loop is
+// COUNTED -- s_waitcnt vmcnt(KQ): everything but the previous row's stores (loads and stores retire in order on one counter).
 #include "common.h"
 #include <stdlib.h>
 
@@ -21,13 +29,17 @@ struct RowsArgs {
     const float* ep_scale;
     const float* ep_shift;
     int ep_relu;
-    unsigned xbytes;
+    unsigned xbytes, ybytes;
     int N, H, W, ldx, P, Q, ldy, ph, pw;
     int rseg, nseg, mtiles;
     int Pp, Qp;             // POOL: the pooled output [N,Pp,Qp,ldy] is what is written
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef unsigned u32x2r_t __attribute__((ext_vector_type(2)));
+#define ROWS_DSREAD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define ROWS_DSREAD_OFF(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define ROWS_DSWRITE64_OFF(addr, val, OFF) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(OFF) : "memory")
 constexpr int RSEG = 16;        // output rows per block
 constexpr int MT_MAX = 10;      // 16-pixel tiles per output row (Q <= 160)
 constexpr int NPX = 16 * MT_MAX + 4;   // pixels of an LDS row image: input columns -2 .. 16*MT_MAX+1
@@ -37,8 +49,11 @@ constexpr int NPX = 16 * MT_MAX + 4;   // pixels of an LDS row image: input colu
 // items in registers over the three conv rows of a pooled row and writes the pooled row; a block owns 8 pooled rows = 17 conv rows (the
 // last one is the next block's first: recomputed).  Bit-identical to the affine epilogue followed by ifcbk_maxpool_fwd (rounding to the
 // storage type is monotone), without the 708 MB activation write and read per batch of 256.
-template <int CIN, int COUT, bool POOL = false>
+// EPI: 0 raw store (input gradients), 1 raw store + BatchNorm statistics (training forward), 2 folded-BatchNorm affine (+ReLU) (eval) --
+// a template parameter so that the statistics / coefficient registers exist only where they are used (<64, 32> spilled otherwise)
+template <int CIN, int COUT, int EPI, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
+    static_assert(!POOL || EPI == 2, "the pooled form is the eval epilogue");
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel
     constexpr int NTL = COUT / 16;                   // output-channel tiles
     constexpr int KG = CIN / 32;                     // MFMA k groups per tap
@@ -47,8 +62,9 @@ __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
     constexpr int NDMA = (NPX * CPP + 63) / 64;      // LDS-DMA wave-instructions per input row
     constexpr int JD = (NDMA + 3) / 4;               // per wave
     constexpr int SLOT = NDMA * 512;                 // elements per row slot: whole DMA pieces (the tail piece writes zeros)
-    // 4 slots: the next input row is in flight while a row is multiplied.  64 input channels: 3 slots (the next row is
-    // requested right after the multiply and lands during the epilogue) so that two blocks still fit a CU
+    // 4 slots: the next input row is in flight while a row is multiplied (a fifth slot, two rows in flight, measured no better:
+    // 21.21 vs 21.19 ms per step).  64 input channels: 3 slots (the next row is requested right after the multiply and lands during
+    // the epilogue) so that two blocks still fit a CU
     constexpr int NSLOT = CIN == 32 ? 4 : 3;
     __shared__ __attribute__((aligned(16))) bf16_t sRow[NSLOT * SLOT];
     __shared__ __attribute__((aligned(16))) bf16_t sC[16 * MT_MAX * LDC];
@@ -105,20 +121,53 @@ __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
             }                                                                                                   \
     }
 
-    // ---- per-lane fragment byte offsets of the pixel operand for the three column shifts
-    // pixel of lane = q0 + frow + s - pw + 2  (LDS index); chunk = kg*4 + fkg, swizzled by the pixel
-    float s1[8], s2[8];
+    // ---- per-lane LDS byte offsets: pixel fragments (tile mi, column shift s, k group kg) inside a row slot; the tile's C rows
+    // pixel of lane = mt*16 + frow + s - pw + 2  (LDS index); chunk = kg*4 + fkg, swizzled by the pixel
+    const unsigned sRowB = (unsigned)(size_t)(lptr_t)sRow, sCB = (unsigned)(size_t)(lptr_t)sC;
+    // (tile mi of a wave is 64 pixels behind tile mi - 1 -- a multiple of the swizzle period: an immediate offset)
+    unsigned foff[3][KG];
+    const unsigned cwoff = sCB + (unsigned)(((wave * 16 + frow) * LDC + 4 * fkg) * 2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (int sx = 0; sx < 3; ++sx) {
+        const int px = wave * 16 + frow + sx - a.pw + 2;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int ch = kg * 4 + fkg;
+            const int phys = CPP == 4 ? (ch ^ (((px >> 2) & 1) << 1)) : (ch ^ (px & 7));
+            foff[sx][kg] = (unsigned)((px * CIN + phys * 8) * 2);
+        }
+    }
+    // ---- the output row: thread t owns channel chunk t % CPO of pixels t / CPO + k * (256 / CPO); KQ store instructions per row
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.ybytes, 0x00020000);
+    constexpr int KQ = (16 * MT_MAX * CPO + 255) / 256;
+    const int enn = (t % CPO) * 8;
+    float esc[EPI == 2 ? 8 : 1], esh[EPI == 2 ? 8 : 1];         // eval coefficients of this thread's chunk: loaded once, not per row behind the row's stores
+    if (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { esc[j] = a.ep_scale[enn + j]; esh[j] = a.ep_shift[enn + j]; }
+    }
+    float s1[EPI == 1 ? 8 : 1], s2[EPI == 1 ? 8 : 1];
+    if (EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    }
 
     const int h_first = p0 - a.ph;
     ISSUE_ROW(h_first)
     ISSUE_ROW(h_first + 1)
     ISSUE_ROW(h_first + 2)
     for (int p = p0; p < p1; ++p) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                              // rows p-ph .. p-ph+2 are in LDS; sC of the previous row is consumed
+        // Row p+2 was requested one iteration ago, in front of that iteration's stores: it has landed when nothing but those stores
+        // is outstanding (loads and stores retire in order on one counter)
+        const int prel = p - p0 - 1;                  // POOL: the previous row stored iff it completed a pooled row (even, > 0)
+        const bool prev_stored = POOL ? (prel > 0 && !(prel & 1)) : p > p0;
+        if (prev_stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(POOL ? NI : KQ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // rows p-ph .. p-ph+2 are in LDS; every wave is done reading sC of the previous row
         if (NSLOT == 4 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // prefetch: its slot held row p-ph-1, no longer needed
+        unsigned sb[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sb[r] = sRowB + (unsigned)(((p - a.ph + r + 6) % NSLOT) * SLOT * 2);
 #pragma unroll
         for (int mi = 0; mi < 3; ++mi) {
             const int mt = wave + 4 * mi;
@@ -126,56 +175,71 @@ __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
             f32x4_t acc[NTL];
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            // fragments of filter row r + 1 are requested before the MFMAs of row r
+            bf16x8_t xb[2][3][KG];
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) ROWS_DSREAD_OFF(xb[0][sx][kg], sb[0] + foff[sx][kg], mi * 64 * CIN * 2);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const bf16_t* rowp = sRow + ((p - a.ph + r + 6) % NSLOT) * SLOT;
+                if (r < 2) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int px = mt * 16 + frow + s - a.pw + 2;
+                    for (int sx = 0; sx < 3; ++sx)
 #pragma unroll
-                    for (int kg = 0; kg < KG; ++kg) {
-                        const int ch = kg * 4 + fkg;
-                        const int phys = CPP == 4 ? (ch ^ (((px >> 2) & 1) << 1)) : (ch ^ (px & 7));
-                        const bf16x8_t xb = *reinterpret_cast<const bf16x8_t*>(rowp + px * CIN + phys * 8);
+                        for (int kg = 0; kg < KG; ++kg) ROWS_DSREAD_OFF(xb[(r + 1) & 1][sx][kg], sb[r + 1] + foff[sx][kg], mi * 64 * CIN * 2);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * KG) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
                         for (int nt = 0; nt < NTL; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r * 3 + s][nt][kg], xb, acc[nt], 0, 0, 0);
-                    }
-                }
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r * 3 + sx][nt][kg], xb[r & 1][sx][kg], acc[nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // lane holds channels nt*16 + 4*(lane>>4) .. +3 of pixel mt*16 + frow
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
-                uint2 u;
-                u.x = pack2bf(acc[nt][0], acc[nt][1]);
-                u.y = pack2bf(acc[nt][2], acc[nt][3]);
-                *reinterpret_cast<uint2*>(sC + (mt * 16 + frow) * LDC + nt * 16 + 4 * fkg) = u;
+                const u32x2r_t u = {pack2bf(acc[nt][0], acc[nt][1]), pack2bf(acc[nt][2], acc[nt][3])};
+                ROWS_DSWRITE64_OFF(cwoff, u, mi * 64 * LDC * 2 + nt * 32);
             }
         }
-        __syncthreads();
-        if (NSLOT == 3 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // the slot of row p-ph is free: every wave is past its multiply
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // the C row is complete; every wave is past its multiply
+        if (NSLOT == 3 && p + 1 < p1) ISSUE_ROW(p - a.ph + 3)        // the slot of row p-ph is free
         // ---- output row: 16-byte chunks, thread t always owns channel chunk t % CPO
         if (POOL) {
-            const int cc = t % CPO, nn = cc * 8;
-            float sc[8], sh[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sc[j] = a.ep_scale[nn + j]; sh[j] = a.ep_shift[nn + j]; }
             const int rel = p - p0;
+            u32x4_t cv[NI][3];
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 const int qq = (t + 256 * k) / CPO;
-                if (qq >= a.Qp) break;
+                const int qs = qq < a.Qp ? qq : 0;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) ROWS_DSREAD(cv[k][sx], sCB + (unsigned)(((2 * qs + sx) * LDC + enn) * 2));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int qq = (t + 256 * k) / CPO;
+                const bool live = qq < a.Qp;
                 float h[8];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
+                for (int sx = 0; sx < 3; ++sx) {
                     float fv[8];
-                    Chunk<bf16_t>::load(sC + (2 * qq + s) * LDC + nn, fv);
+                    unpack8(uint4{cv[k][sx][0], cv[k][sx][1], cv[k][sx][2], cv[k][sx][3]}, fv);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        float v = fv[j] * sc[j] + sh[j];
+                        float v = fv[j] * esc[j] + esh[j];
                         if (a.ep_relu) v = fmaxf(v, 0.f);
                         v = Chunk<bf16_t>::round(v);
-                        h[j] = s ? fmaxf(h[j], v) : v;
+                        h[j] = sx ? fmaxf(h[j], v) : v;
                     }
                 }
                 if (rel) {
@@ -186,7 +250,9 @@ __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
                     if (rel & 1) {
                         run[k] = pack8(rv);
                     } else {
-                        Chunk<bf16_t>::store((bf16_t*)a.y + ((size_t)(n * a.Pp + (p >> 1) - 1) * a.Qp + qq) * a.ldy + nn, rv);
+                        const uint4 o = pack8(rv);
+                        const unsigned off = live ? (unsigned)((((size_t)(n * a.Pp + (p >> 1) - 1) * a.Qp + qq) * a.ldy + enn) * 2) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o.x, o.y, o.z, o.w}, rsY, off, 0, 0);
                         run[k] = pack8(h);
                     }
                 } else {
@@ -194,34 +260,41 @@ __global__ __launch_bounds__(256, 2) void conv_rows3x3(RowsArgs a) {
                 }
             }
         } else {
-            const int cc = t % CPO;
-            const int nn = cc * 8;
-            float sc[8], sh[8];
-            if (a.ep_scale) {
+            const unsigned yrow = (unsigned)((((size_t)(n * a.P + p) * a.Q) * a.ldy + enn) * 2);
+            u32x4_t cv[KQ];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { sc[j] = a.ep_scale[nn + j]; sh[j] = a.ep_shift[nn + j]; }
+            for (int k = 0; k < KQ; ++k) {
+                const int q = t / CPO + k * (256 / CPO);
+                ROWS_DSREAD(cv[k], sCB + (unsigned)((((q < a.Q) ? q : 0) * LDC + enn) * 2));
             }
-            bf16_t* yrow = (bf16_t*)a.y + ((size_t)(n * a.P + p) * a.Q) * a.ldy + nn;
-            for (int q = t / CPO; q < a.Q; q += 256 / CPO) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) {
+                const int q = t / CPO + k * (256 / CPO);
+                const bool live = q < a.Q;
                 float fv[8];
-                Chunk<bf16_t>::load(sC + q * LDC + nn, fv);
-                if (a.part) {
+                unpack8(uint4{cv[k][0], cv[k][1], cv[k][2], cv[k][3]}, fv);
+                if (EPI == 1 && live) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { s1[j] += fv[j]; s2[j] += fv[j] * fv[j]; }
                 }
-                if (a.ep_scale) {
+                u32x4_t o = cv[k];
+                if (EPI == 2) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        fv[j] = fv[j] * sc[j] + sh[j];
+                        fv[j] = fv[j] * esc[j] + esh[j];
                         if (a.ep_relu) fv[j] = fmaxf(fv[j], 0.f);
                     }
+                    const uint4 pk = pack8(fv);
+                    o = u32x4_t{pk.x, pk.y, pk.z, pk.w};
                 }
-                Chunk<bf16_t>::store(yrow + (size_t)q * a.ldy, fv);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsY, live ? yrow + (unsigned)(q * a.ldy * 2) : OOB, 0, 0);
             }
         }
     }
 #undef ISSUE_ROW
-    if (a.part) {
+    if (EPI == 1) {
         // threads with the same channel chunk (t % CPO) -> one partial row per block, fixed order
 #pragma unroll
         for (int off = CPO; off < 64; off <<= 1)
@@ -270,13 +343,25 @@ int ifcbk_conv_rows_launch(ifcbk_ctx* ctx, int cin, int cout, int N, int H, int 
     RowsArgs a;
     a.x = x; a.w = w; a.y = y; a.part = part; a.ep_scale = scale; a.ep_shift = shift; a.ep_relu = relu;
     a.xbytes = (unsigned)((int64_t)N * H * W * ldx * 2);
+    if ((int64_t)N * P * Q * ldy * 2 >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_rows3x3: the output exceeds the 2 GiB descriptor window");
+    a.ybytes = (unsigned)((int64_t)N * P * Q * ldy * 2);
     a.N = N; a.H = H; a.W = W; a.ldx = ldx; a.P = P; a.Q = Q; a.ldy = ldy; a.ph = pad_h; a.pw = pad_w;
     a.rseg = RSEG; a.nseg = (P + RSEG - 1) / RSEG; a.mtiles = (Q + 15) / 16;
     a.Pp = a.Qp = 0;
     const dim3 grid(N * a.nseg), block(256);
-    if (cin == 32 && cout == 32) hipLaunchKernelGGL((conv_rows3x3<32, 32>), grid, block, 0, st, a);
-    else if (cin == 32 && cout == 64) hipLaunchKernelGGL((conv_rows3x3<32, 64>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_rows3x3<64, 32>), grid, block, 0, st, a);
+    if ((part != nullptr) && (scale != nullptr)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_rows3x3: statistics and the affine epilogue exclude each other");
+    if ((scale != nullptr) != (shift != nullptr)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_rows3x3: scale and shift come together");
+    const int epi = part ? 1 : (scale ? 2 : 0);
+#define IFCBK_ROWS_LAUNCH(CI, CO)                                                                       \
+    {                                                                                                   \
+        if (epi == 1) hipLaunchKernelGGL((conv_rows3x3<CI, CO, 1>), grid, block, 0, st, a);             \
+        else if (epi == 2) hipLaunchKernelGGL((conv_rows3x3<CI, CO, 2>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((conv_rows3x3<CI, CO, 0>), grid, block, 0, st, a);                      \
+    }
+    if (cin == 32 && cout == 32) IFCBK_ROWS_LAUNCH(32, 32)
+    else if (cin == 32 && cout == 64) IFCBK_ROWS_LAUNCH(32, 64)
+    else IFCBK_ROWS_LAUNCH(64, 32)
+#undef IFCBK_ROWS_LAUNCH
     IFCBK_LAUNCH_CHECK(ctx, "conv_rows3x3");
     return 0;
 }
@@ -293,8 +378,10 @@ int ifcbk_conv_rows_pool_launch(ifcbk_ctx* ctx, int N, int H, int W, int ldx, in
     a.xbytes = (unsigned)((int64_t)N * H * W * ldx * 2);
     a.N = N; a.H = H; a.W = W; a.ldx = ldx; a.P = P; a.Q = Q; a.ldy = ldy; a.ph = pad_h; a.pw = pad_w;
     a.Pp = (P - 3) / 2 + 1; a.Qp = (Q - 3) / 2 + 1;
+    if ((int64_t)N * a.Pp * a.Qp * ldy * 2 >= (1ll << 31)) IFCBK_FAIL(ctx, IFCBK_EINVAL, "conv_rows3x3(pool): the output exceeds the 2 GiB descriptor window");
+    a.ybytes = (unsigned)((int64_t)N * a.Pp * a.Qp * ldy * 2);
     a.rseg = RSEG; a.nseg = (a.Pp + RSEG / 2 - 1) / (RSEG / 2); a.mtiles = (Q + 15) / 16;
-    hipLaunchKernelGGL((conv_rows3x3<32, 64, true>), dim3(N * a.nseg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_rows3x3<32, 64, 2, true>), dim3(N * a.nseg), dim3(256), 0, st, a);
     IFCBK_LAUNCH_CHECK(ctx, "conv_rows3x3(pool)");
     return 0;
 }

@@ -9,6 +9,7 @@ LAYERS = {
     # name: N, C, H, W, K, R, S, sh, sw, ph, pw
     '2a_3x3':   (256, 32, 149, 149, 32, 3, 3, 1, 1, 0, 0),
     '2b_3x3':   (256, 32, 147, 147, 64, 3, 3, 1, 1, 1, 1),
+    '3b_1x1':   (256, 64, 73, 73, 80, 1, 1, 1, 1, 0, 0),
     '4a_3x3':   (256, 80, 73, 73, 192, 3, 3, 1, 1, 0, 0),
     '5b_5x5':   (256, 48, 35, 35, 64, 5, 5, 1, 1, 2, 2),
     '5c_3x3b':  (256, 96, 35, 35, 96, 3, 3, 1, 1, 1, 1),
