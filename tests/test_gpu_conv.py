@@ -55,6 +55,7 @@ CASES = [
     (1, 32, 20, 149, 32, 3, 3, 1, 1, 0, 0),        # ... full 149-wide rows (10 pixel tiles), two row segments
     (3, 32, 35, 18, 32, 3, 3, 1, 1, 0, 0),         # ... three row segments per image
     (2, 32, 37, 147, 64, 3, 3, 1, 1, 1, 1),        # row-streaming stem weight gradient: full-width rows, pad 1, two K halves, 3 strips
+    (2, 64, 19, 23, 32, 3, 3, 1, 1, 1, 1),         # row-streaming kernel, 64 -> 32 forward with statistics (its input gradient: 32 -> 64 raw)
     (2, 80, 21, 73, 192, 3, 3, 1, 1, 0, 0),        # ... its 80-channel form (Conv2d_4a): six K blocks, 104-pixel row images
 ]
 
@@ -124,6 +125,35 @@ def test_conv_fwd_dgrad_wgrad(ctx, case):
     rdw = wr.grad.permute(0, 2, 3, 1)
     err = (dw.cpu() - rdw).abs().max().item()
     assert err <= 2e-5 * max(1.0, rdw.abs().max().item()) * (N * P * Q) ** 0.5, err
+
+
+@pytest.mark.parametrize('case', [(2, 32, 20, 149, 32, 3, 3, 1, 1, 0, 0), (2, 32, 21, 19, 64, 3, 3, 1, 1, 1, 1),
+                                  (2, 64, 19, 23, 32, 3, 3, 1, 1, 1, 1)])
+@pytest.mark.parametrize('relu', [0, 1])
+def test_row_streaming_kernel_affine_epilogue(ctx, case, relu):
+    """conv_rows3x3<.., .., 2> (the eval epilogue of the row-streaming kernel, every channel pair it serves): y = act(conv * scale +
+    shift) must be the raw forward's ROUNDED output put through the same affine -- same kernel body, only the epilogue differs"""
+    from ifcb_classifier_amd import _lib
+    N, Cc, H, W, K, R, S, sh, sw, ph, pw = case
+    g = torch.Generator().manual_seed(7 + K + relu)
+    x = nhwc(_bf(torch.randn(N, Cc, H, W, generator=g)))
+    wk = (torch.randn(K, R, S, Cc, generator=g) * (1.0 / (Cc * R * S) ** 0.5)).to(torch.bfloat16).cuda()
+    scale = (torch.rand(K, generator=g) + 0.5).cuda()
+    shift = torch.randn(K, generator=g).cuda()
+    d = _desc(_lib, *case)
+    st = _lib.cur_stream()
+    raw = torch.full((N, d.P, d.Q, K), float('nan'), dtype=torch.bfloat16, device='cuda')
+    mb = ctx.lib.ifcbk_conv2d_fwd_mblocks(C.byref(d))
+    part = torch.zeros(mb, 2, K, dtype=torch.float32, device='cuda')
+    ctx.call('ifcbk_conv2d_fwd', C.byref(d), _lib.ptr(x), _lib.ptr(wk), _lib.ptr(raw), _lib.ptr(part), st)
+    got = torch.full((N, d.P, d.Q, K), float('nan'), dtype=torch.bfloat16, device='cuda')
+    ctx.call('ifcbk_conv2d_fwd_affine', C.byref(d), _lib.ptr(x), _lib.ptr(wk), _lib.ptr(got), _lib.ptr(scale), _lib.ptr(shift), None, 0, relu, st)
+    torch.cuda.synchronize()
+    # (the kernel's affine is one fused multiply-add: emulate the single rounding through double)
+    want = (raw.double() * scale.double() + shift.double()).float()
+    if relu:
+        want = want.clamp_min(0)
+    assert torch.equal(got, want.to(torch.bfloat16))
 
 
 def test_conv_channel_slices(ctx):
