@@ -402,7 +402,10 @@ bool ifcbk_conv_big_plan(int dtype, int M, int K, int Kg, int* mt_out, int* tn_o
         }
     if (!bmt) return false;
     const int64_t tiles = (int64_t)cdiv(M, 32 * bmt) * cdiv(K, 64 * btn);
-    if (mode < 2 && (tiles < (3 * cus) / 4 || tiles > 6 * cus)) return false;
+    // grids of many rounds: only with the 256-channel tile (the sibling 1x1 GEMMs of large RUN batches: one pass over the block input
+    // instead of two or three 128-channel column tiles -- at batch 2048 Mixed_5b-5d / 6b-6e 0.76-1.00 -> 0.69-0.90 ms each; the
+    // 192-channel tiles lose there: Conv2d_4a 0.95x, Mixed_7b / 7c 0.87-0.89x)
+    if (mode < 2 && (tiles < (3 * cus) / 4 || (tiles > 6 * cus && btn != 4))) return false;
     if (mt_out) *mt_out = bmt;
     if (tn_out) *tn_out = btn;
     return true;
