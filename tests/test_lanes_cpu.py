@@ -142,3 +142,62 @@ def test_program_lane_default_follows_the_job_size_not_the_construction_order(mo
     e1 = Engine(net, max_batch=2, plan_only=True)
     with pytest.raises(RuntimeError, match='dp_world'):
         e1.train_step_ddp(2, 8, lambda *a, **k: None)
+
+
+def test_bucketed_optimizer_waits_for_its_gradients_and_the_repack_for_the_readers_of_the_shadows():
+    """round 5: the fused train step runs the optimizer and the bf16 repack PER BUCKET of the flat gradient buffer, on the
+    weight-gradient lane, while backward is still running (engine._bucketed_update).  On the frozen step program of inception_v3
+    (lanes and wait masks as ctx.hip::run_lanes will see them): the buckets tile the parameter buffer; every op that writes a
+    gradient happens-before the optimizer launch of its bucket; a bucket's repack happens-after its optimizer launch AND after
+    every input-gradient op that still reads the bf16 shadows it rewrites.  ref neuston_models.py:63-64,81-86: optimizer.step()
+    after loss.backward() -- per parameter that order is all the reference's arithmetic depends on."""
+    from ifcb_classifier_amd import graph, _lib
+    from ifcb_classifier_amd.engine import Engine
+    eng = Engine(graph.build('inception_v3', 7), max_batch=2, plan_only=True)
+    pl = eng.plan(2)
+    arr, n, tags = pl.step.arr, pl.step.n, pl.step.tags
+    sched = [((arr[k].flags >> 8) & 7, (arr[k].flags >> 12) & 0xff) for k in range(n)]
+    reach = _happens_before(sched)
+    base = eng.G.data_ptr()
+    adam = pl.step_adam_idxs
+    assert len(adam) >= 2 and adam == sorted(adam)
+    rng = [((arr[k].p[1] - base) // 4, int(arr[k].i[0])) for k in adam]
+    lo_sorted = sorted(rng)
+    assert lo_sorted[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(lo_sorted, lo_sorted[1:]))
+    assert lo_sorted[-1][0] + lo_sorted[-1][1] == eng.nparam_padded
+
+    def bucket_of(off):
+        for b, (lo, cnt) in enumerate(rng):
+            if lo <= off < lo + cnt:
+                return b
+        raise AssertionError(off)
+    # ---- every gradient writer happens-before its bucket's optimizer launch
+    nwriters, off_of_layer = 0, {}
+    for j in range(n):
+        offs = eng._op_param_offsets(arr[j])
+        for off in offs:
+            b = bucket_of(off)
+            assert j < adam[b] and j in reach[adam[b]], (tags[j], b)
+            nwriters += 1
+        # conv weight gradients: remember which parameter offset belongs to which layer name
+        k = arr[j].kind
+        if k == _lib.OP_CONV_WGRAD or k == _lib.OP_STEM_U8_WGRAD:
+            off_of_layer[tags[j]] = offs[0]
+        elif k in (_lib.OP_CONV_WGRAD_SEG, _lib.OP_CONV_WGRAD_GROUP):
+            for name, off in zip(tags[j].split('+'), offs):
+                off_of_layer[name] = off
+    assert nwriters > 250 and len(off_of_layer) >= 94
+    # ---- the repack of bucket b: after its optimizer launch, after every reader of the shadows it rewrites
+    packs = pl.step.find(_lib.OP_WEIGHT_PACK_MULTI)
+    assert len(packs) == len(adam)
+    for b, (a, pk) in enumerate(zip(adam, packs)):
+        assert a < pk and a in reach[pk], b
+    dkinds = (_lib.OP_CONV_DGRAD, _lib.OP_CONV_DGRAD_BNSTAT, _lib.OP_CONV_DGRAD_BNSTAT_TAB)
+    nreaders = 0
+    for j in range(n):
+        if arr[j].kind in dkinds:
+            for name in tags[j].split('+'):
+                pk = packs[bucket_of(off_of_layer[name])]
+                assert j < pk and j in reach[pk], (tags[j], name)
+                nreaders += 1
+    assert nreaders >= 90
